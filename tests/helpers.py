@@ -1,0 +1,85 @@
+"""Shared helpers for the parity tests: golden-fixture access and the three small
+functions tests/golden/make_golden.py used to build inputs and digests."""
+import gzip
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+MODEL_CASES = ["cfg1_b3", "cfg2_b4", "circle2_b2", "tidal_b3", "odd_k5_b5", "s3_b4", "counts_b3",
+               "handspec_b4"]
+
+
+def projections(arr, seed, nproj=8):
+    flat = np.asarray(arr, dtype=np.float64).reshape(-1)
+    rng = np.random.default_rng(seed)
+    out = np.zeros(nproj, dtype=np.float64)
+    for k in range(nproj):
+        signs = rng.integers(0, 2, size=flat.size, dtype=np.int8).astype(np.float64) * 2.0 - 1.0
+        out[k] = float(np.dot(flat, signs))
+    return out
+
+
+def subsample(arr, step=5):
+    return np.ascontiguousarray(np.asarray(arr)[..., ::step, ::step])
+
+
+class GoldenCase:
+    def __init__(self, name):
+        self.name = name
+        with open(os.path.join(GOLDEN, name + ".json")) as f:
+            self.meta = json.load(f)
+        self.npz = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+        self.spec = self.meta["spec"]
+
+    def __getitem__(self, key):
+        return self.npz[key]
+
+    def keys(self):
+        return self.npz.files
+
+    def group(self, prefix):
+        """OrderedDict of arrays under `prefix`, keys stripped of it, in file order"""
+        out = OrderedDict()
+        for k in self.npz.files:
+            if k.startswith(prefix):
+                out[k[len(prefix):]] = self.npz[k]
+        return out
+
+    @property
+    def x(self):
+        return self.npz["x"]
+
+    @property
+    def t(self):
+        return self.npz["t_u8"].astype(np.float32) / 256.0
+
+    @property
+    def x2(self):
+        return self.npz["x2"]
+
+    @property
+    def t2(self):
+        return self.npz["t2_u8"].astype(np.float32) / 256.0
+
+
+def load_sizer_sweep():
+    with gzip.open(os.path.join(GOLDEN, "model_sizer.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+def bn_bias_keys(spec):
+    """state_dict keys of conv biases that feed a BatchNorm: their gradient is exactly zero in
+    exact arithmetic (BN removes any per-channel constant), so the reference's value is pure
+    rounding noise and Adam turns it into +-lr steps of arbitrary sign.  Parity for these keys
+    is checked on magnitude only (see DESIGN.md 'Bias before BatchNorm')."""
+    keys = set()
+    for i in range(len(spec["input_layers"])):
+        keys.add(f"enc/encoder_cnn.{3 * i}.bias")
+    n = len(spec["output_layers"])
+    for i in range(n - 1):
+        keys.add(f"dec/decoder_conv.{3 * i}.bias")
+    return keys
