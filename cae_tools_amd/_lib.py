@@ -1,0 +1,83 @@
+"""ctypes binding of libcae_hip.so (C ABI: include/cae_hip.h).  Fails loudly when the library
+is missing: there is no other compute path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcae_hip.so")
+
+
+class CaeError(RuntimeError):
+    pass
+
+
+class LayerSpecC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("in_c", "in_h", "in_w", "out_c", "out_h", "out_w", "k_h", "k_w",
+                                          "stride", "output_padding")]
+
+
+class TensorInfoC(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("arena", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
+                ("offset", C.c_int64), ("numel", C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/cae_hip.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "cae_last_error": (C.c_char_p, []),
+    "cae_abi_version": (C.c_int, []),
+    "cae_engine_create": (C.c_int, [C.POINTER(LayerSpecC), C.c_int, C.POINTER(LayerSpecC), C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.POINTER(_P)]),
+    "cae_engine_destroy": (None, [_P]),
+    "cae_param_count": (C.c_int64, [_P]),
+    "cae_buffer_count": (C.c_int64, [_P]),
+    "cae_tensor_count": (C.c_int, [_P]),
+    "cae_tensor_info": (C.c_int, [_P, C.c_int, C.POINTER(TensorInfoC)]),
+    "cae_workspace_bytes": (C.c_int64, [_P]),
+    "cae_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64]),
+    "cae_set_stream": (C.c_int, [_P, _P]),
+    "cae_set_graph_mode": (C.c_int, [_P, C.c_int]),
+    "cae_set_hyper": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "cae_set_dataset": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
+    "cae_set_cursor": (C.c_int, [_P, C.c_int64, C.c_int]),
+    "cae_set_adam_step": (C.c_int, [_P, C.c_int]),
+    "cae_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "cae_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
+    "cae_adam_step": (C.c_int, [_P]),
+    "cae_eval_step": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "cae_score": (C.c_int, [_P, _P, C.c_int, _P]),
+    "cae_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "cae_loss_slots": (C.c_int, [_P]),
+    "cae_sync": (C.c_int, [_P]),
+    "cae_debug_read": (C.c_int64, [_P, C.c_char_p, C.c_int, _P, C.c_int64]),
+    "cae_scan_f32": (C.c_int, [_P, C.c_int64, _P, C.POINTER(C.c_double)]),
+    "cae_normalise_pack": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_float,
+                                     C.c_float, C.c_int, _P]),
+    "cae_denormalise_f64": (C.c_int, [_P, C.c_int64, C.c_double, C.c_double, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CaeError(f"{LIB_PATH} is missing: build it with `python -m cae_tools_amd.build` "
+                       "(hipcc --offload-arch=gfx950). cae_tools_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch, surfaced loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc is not None and rc < 0:
+        msg = load().cae_last_error()
+        raise CaeError(f"libcae_hip error {rc}: {msg.decode() if msg else '?'}")
+    return rc

@@ -1,0 +1,906 @@
+// engine.hip — host side of libcae_hip.so: launch plan, workspace carving, hipGraph capture
+// and the extern "C" ABI declared in include/cae_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "cae_hip.h"
+#include "kernels_generic.h"
+
+using namespace cae;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(CAE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr float kBnEps = 1e-5f;      // nn.BatchNorm2d default (encoder.py:45, decoder.py:47)
+constexpr float kBnMomentum = 0.1f;  // nn.BatchNorm2d default
+constexpr int kLossSlots = 1 << 16;
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct ConvLayer {
+    bool transposed;
+    int cin, hin, win, cout, hout, wout, kh, kw, stride, opad;
+    bool has_bn;
+    int bn_index;  // index into the BN tables, -1 when has_bn is false
+    int64_t w_off, b_off, gamma_off, beta_off;  // parameter arena (floats)
+    int64_t rm_off, rv_off;                     // buffer arena (floats)
+    int64_t act_off, grad_off;                  // workspace (bytes): raw output y / masked gradient g
+    int64_t out_elems() const { return (int64_t)cout * hout * wout; }
+    int64_t in_elems() const { return (int64_t)cin * hin * win; }
+};
+
+struct FcLayer {
+    int nin, nout;
+    int64_t w_off, b_off;
+    int64_t act_off, grad_off;  // output activation / gradient wrt pre-activation of the output
+    bool relu;
+};
+
+}  // namespace
+
+struct cae_engine {
+    std::vector<ConvLayer> enc, dec;
+    FcLayer fc[4];  // encoder_lin.0, encoder_lin.2, decoder_lin.0, decoder_lin.2
+    int fc_size = 0, latent = 0, max_batch = 0;
+    int in_c = 0, in_h = 0, in_w = 0, out_c = 0, out_h = 0, out_w = 0;
+    std::vector<cae_tensor_info_t> tensors;
+    int64_t n_param = 0, n_buf = 0;
+    int n_bn = 0;
+    std::vector<int64_t> bn_stat_off;   // per BN: byte offset of its [C][4] double sums
+    std::vector<int64_t> bn_saved_off;  // per BN: byte offset of its [C][2] float mean/invstd
+    std::vector<int> bn_channels;
+    int max_channels = 0;
+
+    // workspace carve (byte offsets)
+    int64_t off_state = 0, off_losses = 0, off_zero_begin = 0, off_gradacc = 0, off_zero_end = 0;
+    int64_t off_glast = 0, off_scan = 0;
+    int64_t ws_need = 0;
+
+    // bound memory
+    float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr, *bufs = nullptr;
+    char* ws = nullptr;
+    hipStream_t stream = nullptr;
+    Hyper hp{1e-3, 0.9, 0.999, 1e-8, 1e-5};
+    const float* ds_x[2] = {nullptr, nullptr};
+    const float* ds_t[2] = {nullptr, nullptr};
+    int64_t ds_n[2] = {0, 0};
+    bool graph_mode = true;
+    // key: (op, which, batch, global_batch, perm)
+    std::map<std::tuple<int, int, int, int, const void*>, hipGraphExec_t> graphs;
+
+    StepState* state() const { return reinterpret_cast<StepState*>(ws + off_state); }
+    double* losses() const { return reinterpret_cast<double*>(ws + off_losses); }
+    double* gradacc() const { return reinterpret_cast<double*>(ws + off_gradacc); }
+    double* bn_stats(int j) const { return reinterpret_cast<double*>(ws + bn_stat_off[j]); }
+    float* bn_saved(int j) const { return reinterpret_cast<float*>(ws + bn_saved_off[j]); }
+    float* fptr(int64_t off) const { return reinterpret_cast<float*>(ws + off); }
+    void drop_graphs() {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
+    }
+};
+
+namespace {
+
+void add_tensor(cae_engine* e, const std::string& name, int arena, std::vector<int64_t> shape, int64_t* off_out) {
+    cae_tensor_info_t t;
+    memset(&t, 0, sizeof t);
+    snprintf(t.name, sizeof t.name, "%s", name.c_str());
+    t.arena = arena;
+    t.ndim = (int)shape.size();
+    t.numel = 1;
+    for (size_t i = 0; i < shape.size(); i++) {
+        t.shape[i] = shape[i];
+        t.numel *= shape[i];
+    }
+    int64_t& top = arena == 0 ? e->n_param : e->n_buf;
+    top = align_up(top, 4);  // 16-byte aligned tensors
+    t.offset = top;
+    top += t.numel;
+    *off_out = t.offset;
+    e->tensors.push_back(t);
+}
+
+int64_t carve(int64_t& top, int64_t bytes) {
+    top = align_up(top, 256);
+    int64_t o = top;
+    top += bytes;
+    return o;
+}
+
+// ---- descriptor helpers -----------------------------------------------------------------------
+
+BnDesc bn_none() {
+    BnDesc d;
+    memset(&d, 0, sizeof d);
+    d.mode = BN_NONE;
+    return d;
+}
+
+// BN descriptor of conv layer L's BatchNorm in `mode`; count = elements per channel
+BnDesc bn_of(const cae_engine* e, const ConvLayer& L, int mode, double count, int update) {
+    if (!L.has_bn) return bn_none();
+    BnDesc d;
+    memset(&d, 0, sizeof d);
+    d.mode = mode;
+    d.C = L.cout;
+    d.stats = e->bn_stats(L.bn_index);
+    d.gamma = e->params + L.gamma_off;
+    d.beta = e->params + L.beta_off;
+    d.rmean = e->bufs + L.rm_off;
+    d.rvar = e->bufs + L.rv_off;
+    d.saved = e->bn_saved(L.bn_index);
+    d.count = count;
+    d.momentum = kBnMomentum;
+    d.eps = kBnEps;
+    d.update = update;
+    return d;
+}
+
+Src src_plain(const float* p, int C, int H, int W) {
+    Src s;
+    memset(&s, 0, sizeof s);
+    s.p = p;
+    s.C = C;
+    s.H = H;
+    s.W = W;
+    return s;
+}
+
+Epi epi_plain(float* out) {
+    Epi e;
+    memset(&e, 0, sizeof e);
+    e.kind = EPI_PLAIN;
+    e.out = out;
+    return e;
+}
+
+size_t lds_bytes(int c1, int c2) { return 4 * sizeof(double) + (size_t)(c1 + c2 + 1) * sizeof(float4); }
+
+int grid1(int64_t n) { return (int)((n + 255) / 256); }
+
+// positions per block for k_wgrad: aim for ~2048 blocks in total, at least 256 positions each
+int wgrad_ppb(int64_t positions, int64_t nweights) {
+    int64_t target_blocks = 4096;
+    int64_t nsplit = target_blocks / (nweights > 0 ? nweights : 1);
+    if (nsplit < 1) nsplit = 1;
+    int64_t ppb = (positions + nsplit - 1) / nsplit;
+    if (ppb < 256) ppb = 256;
+    ppb = align_up(ppb, 256);
+    return (int)ppb;
+}
+
+enum Op { OP_TRAIN = 1, OP_FWDBWD = 2, OP_EVAL = 3, OP_ADAM = 4 };
+
+// ---- the step, as a sequence of launches on e->stream -------------------------------------------
+
+struct StepArgs {
+    int which;
+    const int32_t* perm;
+    int batch;
+    int global_batch;
+    bool train;            // train-mode forward (+ backward)
+    bool use_cursor;       // samples come from the dataset through the cursor
+    const float* x_direct; // score(): explicit input batch
+    float* yhat;           // eval: sigmoid output destination (may be nullptr)
+    bool want_loss;        // eval: accumulate MSE into the loss slot
+};
+
+int launch_forward(cae_engine* e, const StepArgs& a) {
+    hipStream_t s = e->stream;
+    const int B = a.batch;
+    const StepState* st = e->state();
+    const int act_mode = a.train ? BN_BATCH : BN_RUNNING;
+
+    // ---- encoder convs (encoder.py:40-46)
+    for (size_t l = 0; l < e->enc.size(); l++) {
+        const ConvLayer& L = e->enc[l];
+        ConvGeom g{B, L.cout, L.hout, L.wout, L.cin, L.hin, L.win, L.kh, L.kw, L.stride};
+        Src big;
+        BnDesc bnb = bn_none();
+        if (l == 0) {
+            big = src_plain(a.x_direct ? a.x_direct : e->ds_x[a.which], L.cin, L.hin, L.win);
+            big.perm = a.x_direct ? nullptr : a.perm;
+            big.use_cursor = a.x_direct ? 0 : 1;
+        } else {
+            const ConvLayer& P = e->enc[l - 1];
+            big = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
+            bnb = bn_of(e, P, act_mode, (double)a.global_batch * P.hout * P.wout, 1);
+        }
+        Epi ep = epi_plain(e->fptr(L.act_off));
+        if (a.train) {
+            ep.kind = EPI_STATS;
+            ep.stats = e->bn_stats(L.bn_index);
+        }
+        dim3 grid(grid1((int64_t)B * L.hout * L.wout), L.cout);
+        hipLaunchKernelGGL(k_down, grid, dim3(256), lds_bytes(L.cin, L.cout), s, g, big, bnb, e->params + L.w_off,
+                           e->params + L.b_off, ep, bn_none(), st);
+    }
+    // ---- encoder_lin / decoder_lin (encoder.py:54-58, decoder.py:31-35)
+    {
+        const ConvLayer& P = e->enc.back();
+        const int hw = P.hout * P.wout;
+        BnDesc bni = bn_of(e, P, act_mode, (double)a.global_batch * hw, 1);
+        const float* in = e->fptr(P.act_off);
+        for (int i = 0; i < 4; i++) {
+            const FcLayer& F = e->fc[i];
+            hipLaunchKernelGGL(k_lin_fwd, dim3(grid1((int64_t)B * F.nout)), dim3(256), lds_bytes(i == 0 ? P.cout : 0, 0),
+                               s, B, F.nin, F.nout, in, i == 0 ? bni : bn_none(), hw, e->params + F.w_off,
+                               e->params + F.b_off, F.relu ? 1 : 0, e->fptr(F.act_off));
+            in = e->fptr(F.act_off);
+        }
+    }
+    // ---- decoder conv-transposes (decoder.py:40-48) + sigmoid (:77) + MSELoss (conv_ae_model.py:303)
+    for (size_t l = 0; l < e->dec.size(); l++) {
+        const ConvLayer& L = e->dec[l];
+        const bool last = l + 1 == e->dec.size();
+        ConvGeom g{B, L.cin, L.hin, L.win, L.cout, L.hout, L.wout, L.kh, L.kw, L.stride};
+        Src small;
+        BnDesc bns = bn_none();
+        if (l == 0) {
+            small = src_plain(e->fptr(e->fc[3].act_off), L.cin, L.hin, L.win);
+        } else {
+            const ConvLayer& P = e->dec[l - 1];
+            small = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
+            bns = bn_of(e, P, act_mode, (double)a.global_batch * P.hout * P.wout, 1);
+        }
+        Epi ep;
+        if (!last) {
+            ep = epi_plain(e->fptr(L.act_off));
+            if (a.train) {
+                ep.kind = EPI_STATS;
+                ep.stats = e->bn_stats(L.bn_index);
+            }
+        } else {
+            memset(&ep, 0, sizeof ep);
+            ep.inv_count = (float)(1.0 / ((double)a.global_batch * L.cout * L.hout * L.wout));
+            ep.losses = e->losses();
+            ep.perm = a.perm;
+            ep.use_cursor = a.use_cursor ? 1 : 0;
+            if (a.train) {
+                ep.kind = EPI_SIGMSE;
+                ep.out = e->fptr(e->off_glast);
+                ep.target = e->ds_t[a.which];
+                ep.bias_acc = e->gradacc() + L.b_off;
+            } else {
+                ep.kind = EPI_SIGOUT;
+                ep.yhat = a.yhat;
+                ep.target = a.want_loss ? e->ds_t[a.which] : nullptr;
+            }
+        }
+        dim3 grid(grid1((int64_t)B * L.hout * L.wout), L.cout);
+        hipLaunchKernelGGL(k_up, grid, dim3(256), lds_bytes(L.cin, L.cout), s, g, small, bns, e->params + L.w_off,
+                           e->params + L.b_off, ep, bn_none(), st);
+    }
+    return CAE_OK;
+}
+
+int launch_backward(cae_engine* e, const StepArgs& a) {
+    hipStream_t s = e->stream;
+    const int B = a.batch;
+    const StepState* st = e->state();
+    double* acc = e->gradacc();
+
+    // ---- decoder, last layer first
+    for (int l = (int)e->dec.size() - 1; l >= 0; l--) {
+        const ConvLayer& L = e->dec[l];
+        const bool last = l + 1 == (int)e->dec.size();
+        ConvGeom g{B, L.cin, L.hin, L.win, L.cout, L.hout, L.wout, L.kh, L.kw, L.stride};
+        // gradient wrt this layer's raw output
+        Src gy;
+        BnDesc bng = bn_none();
+        if (last) {
+            gy = src_plain(e->fptr(e->off_glast), L.cout, L.hout, L.wout);
+        } else {
+            gy = src_plain(e->fptr(L.grad_off), L.cout, L.hout, L.wout);
+            gy.q = e->fptr(L.act_off);
+            bng = bn_of(e, L, BN_BWD, (double)a.global_batch * L.hout * L.wout, 0);
+        }
+        // this layer's input activation
+        Src ain;
+        BnDesc bna = bn_none();
+        if (l == 0) {
+            ain = src_plain(e->fptr(e->fc[3].act_off), L.cin, L.hin, L.win);
+        } else {
+            const ConvLayer& P = e->dec[l - 1];
+            ain = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
+            bna = bn_of(e, P, BN_SAVED, 0, 0);
+        }
+        // weight gradient (+ BN parameter gradients of this layer)
+        {
+            const int64_t nw = (int64_t)L.cin * L.cout * L.kh * L.kw;
+            const int64_t pos = (int64_t)B * L.hin * L.win;
+            const int ppb = wgrad_ppb(pos, nw);
+            BnGradOut bg;
+            memset(&bg, 0, sizeof bg);
+            if (L.has_bn) {
+                bg.stats = e->bn_stats(L.bn_index);
+                bg.gamma_acc = acc + L.gamma_off;
+                bg.beta_acc = acc + L.beta_off;
+                bg.C = L.cout;
+                bg.scale = 1.0;
+            }
+            dim3 grid((unsigned)nw, (unsigned)((pos + ppb - 1) / ppb));
+            hipLaunchKernelGGL(k_wgrad, grid, dim3(256), lds_bytes(L.cin, L.cout), s, g, ain, bna, gy, bng,
+                               acc + L.w_off, ppb, bg, st);
+        }
+        // input gradient
+        {
+            Epi ep;
+            BnDesc bne = bn_none();
+            if (l == 0) {
+                ep = epi_plain(e->fptr(e->fc[3].grad_off));
+            } else {
+                const ConvLayer& P = e->dec[l - 1];
+                ep = epi_plain(e->fptr(P.grad_off));
+                ep.kind = EPI_MASKSTATS;
+                ep.stats = e->bn_stats(P.bn_index);
+                ep.yprev = e->fptr(P.act_off);
+                bne = bn_of(e, P, BN_SAVED, 0, 0);
+            }
+            dim3 grid(grid1((int64_t)B * L.hin * L.win), L.cin);
+            hipLaunchKernelGGL(k_down, grid, dim3(256), lds_bytes(L.cout, L.cin), s, g, gy, bng, e->params + L.w_off,
+                               (const float*)nullptr, ep, bne, st);
+        }
+    }
+    // ---- Linear layers, last first.  grad_off of fc[i] holds dL/d(pre-activation of fc[i] output).
+    {
+        const ConvLayer& P = e->enc.back();
+        const int hw = P.hout * P.wout;
+        for (int i = 3; i >= 0; i--) {
+            const FcLayer& F = e->fc[i];
+            const float* gout = e->fptr(F.grad_off);
+            const float* in = i == 0 ? e->fptr(P.act_off) : e->fptr(e->fc[i - 1].act_off);
+            BnDesc bni = i == 0 ? bn_of(e, P, BN_SAVED, 0, 0) : bn_none();
+            hipLaunchKernelGGL(k_lin_wgrad, dim3(grid1((int64_t)F.nin * F.nout)), dim3(256),
+                               lds_bytes(i == 0 ? P.cout : 0, 0), s, B, F.nin, F.nout, gout, in, bni, hw,
+                               acc + F.w_off, acc + F.b_off);
+            if (i > 0) {
+                const FcLayer& G = e->fc[i - 1];
+                hipLaunchKernelGGL(k_lin_dgrad, dim3(grid1((int64_t)B * F.nin)), dim3(256), lds_bytes(0, 0), s, B,
+                                   F.nin, F.nout, gout, e->params + F.w_off, G.relu ? 1 : 0, e->fptr(G.act_off),
+                                   bn_none(), 1, (double*)nullptr, e->fptr(G.grad_off));
+            } else {
+                dim3 grid(grid1((int64_t)B * hw), P.cout);
+                hipLaunchKernelGGL(k_lin_dgrad, grid, dim3(256), lds_bytes(P.cout, 0), s, B, F.nin, F.nout, gout,
+                                   e->params + F.w_off, 2, e->fptr(P.act_off), bni, hw, e->bn_stats(P.bn_index),
+                                   e->fptr(P.grad_off));
+            }
+        }
+    }
+    // ---- encoder convs
+    for (int l = (int)e->enc.size() - 1; l >= 0; l--) {
+        const ConvLayer& L = e->enc[l];
+        ConvGeom g{B, L.cout, L.hout, L.wout, L.cin, L.hin, L.win, L.kh, L.kw, L.stride};
+        Src gy = src_plain(e->fptr(L.grad_off), L.cout, L.hout, L.wout);
+        gy.q = e->fptr(L.act_off);
+        BnDesc bng = bn_of(e, L, BN_BWD, (double)a.global_batch * L.hout * L.wout, 0);
+        Src ain;
+        BnDesc bna = bn_none();
+        if (l == 0) {
+            ain = src_plain(e->ds_x[a.which], L.cin, L.hin, L.win);
+            ain.perm = a.perm;
+            ain.use_cursor = 1;
+        } else {
+            const ConvLayer& P = e->enc[l - 1];
+            ain = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
+            bna = bn_of(e, P, BN_SAVED, 0, 0);
+        }
+        {
+            const int64_t nw = (int64_t)L.cin * L.cout * L.kh * L.kw;
+            const int64_t pos = (int64_t)B * L.hout * L.wout;
+            const int ppb = wgrad_ppb(pos, nw);
+            BnGradOut bg;
+            memset(&bg, 0, sizeof bg);
+            bg.stats = e->bn_stats(L.bn_index);
+            bg.gamma_acc = acc + L.gamma_off;
+            bg.beta_acc = acc + L.beta_off;
+            bg.C = L.cout;
+            bg.scale = 1.0;
+            dim3 grid((unsigned)nw, (unsigned)((pos + ppb - 1) / ppb));
+            hipLaunchKernelGGL(k_wgrad, grid, dim3(256), lds_bytes(L.cout, L.cin), s, g, gy, bng, ain, bna,
+                               acc + L.w_off, ppb, bg, st);
+        }
+        if (l > 0) {
+            const ConvLayer& P = e->enc[l - 1];
+            Epi ep = epi_plain(e->fptr(P.grad_off));
+            ep.kind = EPI_MASKSTATS;
+            ep.stats = e->bn_stats(P.bn_index);
+            ep.yprev = e->fptr(P.act_off);
+            BnDesc bne = bn_of(e, P, BN_SAVED, 0, 0);
+            dim3 grid(grid1((int64_t)B * L.hin * L.win), L.cin);
+            hipLaunchKernelGGL(k_up, grid, dim3(256), lds_bytes(L.cout, L.cin), s, g, gy, bng, e->params + L.w_off,
+                               (const float*)nullptr, ep, bne, st);
+        }
+    }
+    return CAE_OK;
+}
+
+int launch_op(cae_engine* e, int op, const StepArgs& a) {
+    hipStream_t s = e->stream;
+    if (op == OP_TRAIN || op == OP_FWDBWD) {
+        HIP_TRY(hipMemsetAsync(e->ws + e->off_zero_begin, 0, (size_t)(e->off_zero_end - e->off_zero_begin), s));
+        int rc = launch_forward(e, a);
+        if (rc) return rc;
+        rc = launch_backward(e, a);
+        if (rc) return rc;
+        if (op == OP_TRAIN) {
+            hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
+                               (const double*)e->gradacc(), (const float*)nullptr, e->m, e->v, e->hp,
+                               (const StepState*)e->state());
+            hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), a.batch, 1, 1);
+        } else {
+            hipLaunchKernelGGL(k_acc_to_f32, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param,
+                               (const double*)e->gradacc(), e->grads);
+            hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), a.batch, 1, 0);
+        }
+    } else if (op == OP_EVAL) {
+        int rc = launch_forward(e, a);
+        if (rc) return rc;
+        if (a.use_cursor) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), a.batch, 1, 0);
+    } else if (op == OP_ADAM) {
+        hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
+                           (const double*)nullptr, (const float*)e->grads, e->m, e->v, e->hp,
+                           (const StepState*)e->state());
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), 0, 0, 1);
+    }
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+// run an op either directly or through a cached hipGraph
+int run_op(cae_engine* e, int op, const StepArgs& a, bool cacheable) {
+    // the legacy NULL stream cannot be captured: plain launches there
+    if (!e->graph_mode || !cacheable || e->stream == nullptr) return launch_op(e, op, a);
+    auto key = std::make_tuple(op, a.which, a.batch, a.global_batch, (const void*)a.perm);
+    auto it = e->graphs.find(key);
+    if (it == e->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        int rc = launch_op(e, op, a);
+        hipError_t ce = hipStreamEndCapture(e->stream, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (ce != hipSuccess) return fail(CAE_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        hipGraphExec_t exec = nullptr;
+        hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) return fail(CAE_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+        it = e->graphs.emplace(key, exec).first;
+    }
+    HIP_TRY(hipGraphLaunch(it->second, e->stream));
+    return CAE_OK;
+}
+
+int check_ready(const cae_engine* e, int which, int batch, bool need_target) {
+    if (!e) return fail(CAE_ERR_ARG, "null engine");
+    if (!e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+    if (batch < 1 || batch > e->max_batch) return fail(CAE_ERR_ARG, "batch %d outside [1, %d]", batch, e->max_batch);
+    if (which < 0 || which > 1) return fail(CAE_ERR_ARG, "dataset index %d is not 0 or 1", which);
+    if (!e->ds_x[which]) return fail(CAE_ERR_STATE, "dataset %d has not been set", which);
+    if (need_target && !e->ds_t[which]) return fail(CAE_ERR_STATE, "dataset %d has no target array", which);
+    return CAE_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+
+extern "C" {
+
+const char* cae_last_error(void) { return g_err.c_str(); }
+int cae_abi_version(void) { return 1; }
+
+int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec* dec, int n_dec, int fc_size,
+                      int latent_size, int max_batch, cae_engine** out) {
+    if (!enc || !dec || !out || n_enc < 1 || n_dec < 1) return fail(CAE_ERR_ARG, "need >=1 encoder and decoder layer");
+    if (fc_size < 1 || latent_size < 1 || max_batch < 1) return fail(CAE_ERR_ARG, "fc/latent/max_batch must be >= 1");
+    cae_engine* e = new cae_engine();
+    e->fc_size = fc_size;
+    e->latent = latent_size;
+    e->max_batch = max_batch;
+    auto bad = [&](const char* msg, int i) {
+        delete e;
+        return fail(CAE_ERR_ARG, "layer %d: %s", i, msg);
+    };
+    // ---- geometry checks
+    for (int i = 0; i < n_enc; i++) {
+        const cae_layer_spec& s = enc[i];
+        if (s.stride < 1 || s.k_h < 1 || s.k_w < 1 || s.in_c < 1 || s.out_c < 1) return bad("bad encoder spec", i);
+        if (s.in_h < s.k_h || s.in_w < s.k_w) return bad("encoder kernel larger than input", i);
+        if (s.out_h != (s.in_h - s.k_h) / s.stride + 1 || s.out_w != (s.in_w - s.k_w) / s.stride + 1)
+            return bad("encoder output size != floor((in-k)/stride)+1", i);
+        if (i > 0 && (enc[i - 1].out_c != s.in_c || enc[i - 1].out_h != s.in_h || enc[i - 1].out_w != s.in_w))
+            return bad("encoder layer input does not match previous output", i);
+    }
+    for (int i = 0; i < n_dec; i++) {
+        const cae_layer_spec& s = dec[i];
+        if (s.stride < 1 || s.k_h < 1 || s.k_w < 1 || s.in_c < 1 || s.out_c < 1) return bad("bad decoder spec", i);
+        if (s.output_padding < 0 || (s.output_padding >= s.stride && s.output_padding > 0))
+            return bad("output_padding must be smaller than stride", i);
+        if (s.out_h != (s.in_h - 1) * s.stride + s.k_h + s.output_padding ||
+            s.out_w != (s.in_w - 1) * s.stride + s.k_w + s.output_padding)
+            return bad("decoder output size != (in-1)*stride+k+output_padding", i);
+        if (i > 0 && (dec[i - 1].out_c != s.in_c || dec[i - 1].out_h != s.in_h || dec[i - 1].out_w != s.in_w))
+            return bad("decoder layer input does not match previous output", i);
+    }
+    e->in_c = enc[0].in_c;
+    e->in_h = enc[0].in_h;
+    e->in_w = enc[0].in_w;
+    e->out_c = dec[n_dec - 1].out_c;
+    e->out_h = dec[n_dec - 1].out_h;
+    e->out_w = dec[n_dec - 1].out_w;
+
+    // ---- parameter / buffer arenas in the reference's state_dict order
+    int bn = 0;
+    for (int i = 0; i < n_enc; i++) {
+        const cae_layer_spec& s = enc[i];
+        ConvLayer L{};
+        L.transposed = false;
+        L.cin = s.in_c; L.hin = s.in_h; L.win = s.in_w;
+        L.cout = s.out_c; L.hout = s.out_h; L.wout = s.out_w;
+        L.kh = s.k_h; L.kw = s.k_w; L.stride = s.stride; L.opad = 0;
+        L.has_bn = true;
+        L.bn_index = bn++;
+        const std::string c = "enc/encoder_cnn." + std::to_string(3 * i);
+        const std::string b = "enc/encoder_cnn." + std::to_string(3 * i + 1);
+        add_tensor(e, c + ".weight", 0, {L.cout, L.cin, L.kh, L.kw}, &L.w_off);
+        add_tensor(e, c + ".bias", 0, {L.cout}, &L.b_off);
+        add_tensor(e, b + ".weight", 0, {L.cout}, &L.gamma_off);
+        add_tensor(e, b + ".bias", 0, {L.cout}, &L.beta_off);
+        add_tensor(e, b + ".running_mean", 1, {L.cout}, &L.rm_off);
+        add_tensor(e, b + ".running_var", 1, {L.cout}, &L.rv_off);
+        e->enc.push_back(L);
+    }
+    const ConvLayer& EL = e->enc.back();
+    const int flat_enc = EL.cout * EL.hout * EL.wout;
+    const int flat_dec = dec[0].in_c * dec[0].in_h * dec[0].in_w;
+    const int fdims[4][2] = {{flat_enc, fc_size}, {fc_size, latent_size}, {latent_size, fc_size}, {fc_size, flat_dec}};
+    const char* fnames[4] = {"enc/encoder_lin.0", "enc/encoder_lin.2", "dec/decoder_lin.0", "dec/decoder_lin.2"};
+    for (int i = 0; i < 4; i++) {
+        FcLayer& F = e->fc[i];
+        F.nin = fdims[i][0];
+        F.nout = fdims[i][1];
+        F.relu = (i == 0 || i == 2);
+        add_tensor(e, std::string(fnames[i]) + ".weight", 0, {F.nout, F.nin}, &F.w_off);
+        add_tensor(e, std::string(fnames[i]) + ".bias", 0, {F.nout}, &F.b_off);
+    }
+    for (int i = 0; i < n_dec; i++) {
+        const cae_layer_spec& s = dec[i];
+        ConvLayer L{};
+        L.transposed = true;
+        L.cin = s.in_c; L.hin = s.in_h; L.win = s.in_w;
+        L.cout = s.out_c; L.hout = s.out_h; L.wout = s.out_w;
+        L.kh = s.k_h; L.kw = s.k_w; L.stride = s.stride; L.opad = s.output_padding;
+        L.has_bn = i != n_dec - 1;
+        L.bn_index = L.has_bn ? bn++ : -1;
+        const std::string c = "dec/decoder_conv." + std::to_string(3 * i);
+        const std::string b = "dec/decoder_conv." + std::to_string(3 * i + 1);
+        add_tensor(e, c + ".weight", 0, {L.cin, L.cout, L.kh, L.kw}, &L.w_off);
+        add_tensor(e, c + ".bias", 0, {L.cout}, &L.b_off);
+        if (L.has_bn) {
+            add_tensor(e, b + ".weight", 0, {L.cout}, &L.gamma_off);
+            add_tensor(e, b + ".bias", 0, {L.cout}, &L.beta_off);
+            add_tensor(e, b + ".running_mean", 1, {L.cout}, &L.rm_off);
+            add_tensor(e, b + ".running_var", 1, {L.cout}, &L.rv_off);
+        }
+        e->dec.push_back(L);
+    }
+    e->n_param = align_up(e->n_param, 4);
+    e->n_buf = align_up(e->n_buf, 4);
+    e->n_bn = bn;
+
+    // ---- workspace carve
+    int64_t top = 0;
+    e->off_state = carve(top, sizeof(StepState));
+    e->off_losses = carve(top, (int64_t)kLossSlots * sizeof(double));
+    e->off_scan = carve(top, 1024 * 3 * sizeof(double));
+    e->bn_stat_off.resize(bn);
+    e->bn_saved_off.resize(bn);
+    e->bn_channels.resize(bn);
+    e->off_zero_begin = align_up(top, 256);
+    auto reg_bn = [&](const ConvLayer& L) {
+        if (!L.has_bn) return;
+        e->bn_channels[L.bn_index] = L.cout;
+        e->bn_stat_off[L.bn_index] = carve(top, (int64_t)L.cout * 4 * sizeof(double));
+        if (L.cout > e->max_channels) e->max_channels = L.cout;
+    };
+    for (auto& L : e->enc) reg_bn(L);
+    for (auto& L : e->dec) reg_bn(L);
+    e->off_gradacc = carve(top, e->n_param * (int64_t)sizeof(double));
+    e->off_zero_end = align_up(top, 256);
+    top = e->off_zero_end;
+    for (auto& L : e->enc) e->bn_saved_off[L.bn_index] = carve(top, (int64_t)L.cout * 2 * sizeof(float));
+    for (auto& L : e->dec)
+        if (L.has_bn) e->bn_saved_off[L.bn_index] = carve(top, (int64_t)L.cout * 2 * sizeof(float));
+    const int64_t mb = max_batch;
+    for (auto& L : e->enc) {
+        L.act_off = carve(top, mb * L.out_elems() * 4);
+        L.grad_off = carve(top, mb * L.out_elems() * 4);
+    }
+    for (int i = 0; i < 4; i++) {
+        e->fc[i].act_off = carve(top, mb * e->fc[i].nout * 4);
+        e->fc[i].grad_off = carve(top, mb * e->fc[i].nout * 4);
+    }
+    for (auto& L : e->dec) {
+        if (!L.has_bn) continue;
+        L.act_off = carve(top, mb * L.out_elems() * 4);
+        L.grad_off = carve(top, mb * L.out_elems() * 4);
+    }
+    e->off_glast = carve(top, mb * e->dec.back().out_elems() * 4);
+    e->ws_need = align_up(top, 256);
+    for (auto& L : e->enc)
+        if (L.cin > e->max_channels) e->max_channels = L.cin;
+    for (auto& L : e->dec)
+        if (L.cin > e->max_channels) e->max_channels = L.cin;
+    if (lds_bytes(e->max_channels, e->max_channels) > 60 * 1024) {
+        delete e;
+        return fail(CAE_ERR_ARG, "channel count %d exceeds the LDS constant table", e->max_channels);
+    }
+    *out = e;
+    return CAE_OK;
+}
+
+void cae_engine_destroy(cae_engine* e) {
+    if (!e) return;
+    e->drop_graphs();
+    delete e;
+}
+
+int64_t cae_param_count(const cae_engine* e) { return e ? e->n_param : 0; }
+int64_t cae_buffer_count(const cae_engine* e) { return e ? e->n_buf : 0; }
+int cae_tensor_count(const cae_engine* e) { return e ? (int)e->tensors.size() : 0; }
+int cae_tensor_info(const cae_engine* e, int index, cae_tensor_info_t* out) {
+    if (!e || !out || index < 0 || index >= (int)e->tensors.size()) return fail(CAE_ERR_ARG, "tensor index out of range");
+    *out = e->tensors[index];
+    return CAE_OK;
+}
+int64_t cae_workspace_bytes(const cae_engine* e) { return e ? e->ws_need : 0; }
+int cae_loss_slots(const cae_engine*) { return kLossSlots; }
+
+int cae_bind(cae_engine* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* buffers,
+             void* workspace, int64_t workspace_bytes) {
+    if (!e || !params || !grads || !exp_avg || !exp_avg_sq || !buffers || !workspace)
+        return fail(CAE_ERR_ARG, "cae_bind: null pointer");
+    if (workspace_bytes < e->ws_need)
+        return fail(CAE_ERR_ARG, "workspace too small: %lld < %lld", (long long)workspace_bytes, (long long)e->ws_need);
+    if (((uintptr_t)workspace & 255) != 0) return fail(CAE_ERR_ARG, "workspace must be 256-byte aligned");
+    e->drop_graphs();
+    e->params = params;
+    e->grads = grads;
+    e->m = exp_avg;
+    e->v = exp_avg_sq;
+    e->bufs = buffers;
+    e->ws = static_cast<char*>(workspace);
+    return CAE_OK;
+}
+
+int cae_set_stream(cae_engine* e, void* hip_stream) {
+    if (!e) return fail(CAE_ERR_ARG, "null engine");
+    if (e->stream != (hipStream_t)hip_stream) e->drop_graphs();
+    e->stream = (hipStream_t)hip_stream;
+    return CAE_OK;
+}
+
+int cae_set_graph_mode(cae_engine* e, int enabled) {
+    if (!e) return fail(CAE_ERR_ARG, "null engine");
+    e->graph_mode = enabled != 0;
+    if (!e->graph_mode) e->drop_graphs();
+    return CAE_OK;
+}
+
+int cae_set_hyper(cae_engine* e, double lr, double beta1, double beta2, double eps, double weight_decay) {
+    if (!e) return fail(CAE_ERR_ARG, "null engine");
+    Hyper h{lr, beta1, beta2, eps, weight_decay};
+    if (memcmp(&h, &e->hp, sizeof h) != 0) e->drop_graphs();  // hyper-parameters are baked into captured launches
+    e->hp = h;
+    return CAE_OK;
+}
+
+int cae_set_dataset(cae_engine* e, int which, const float* x, const float* t, int64_t n) {
+    if (!e || which < 0 || which > 1 || !x || n < 1) return fail(CAE_ERR_ARG, "cae_set_dataset: bad argument");
+    if (e->ds_x[which] != x || e->ds_t[which] != t) e->drop_graphs();
+    e->ds_x[which] = x;
+    e->ds_t[which] = t;
+    e->ds_n[which] = n;
+    return CAE_OK;
+}
+
+int cae_set_cursor(cae_engine* e, int64_t batch_start, int loss_slot) {
+    if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+    if (loss_slot < 0 || loss_slot >= kLossSlots) return fail(CAE_ERR_ARG, "loss slot out of range");
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, e->stream, e->state(), (long long)batch_start, loss_slot, 1, 0, 0);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_set_adam_step(cae_engine* e, int completed_steps) {
+    if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, e->stream, e->state(), 0LL, 0, 0, completed_steps, 1);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_train_step(cae_engine* e, int which, const int32_t* perm, int batch) {
+    int rc = check_ready(e, which, batch, true);
+    if (rc) return rc;
+    StepArgs a{which, perm, batch, batch, true, true, nullptr, nullptr, true};
+    return run_op(e, OP_TRAIN, a, true);
+}
+
+int cae_forward_backward(cae_engine* e, int which, const int32_t* perm, int batch, int global_batch) {
+    int rc = check_ready(e, which, batch, true);
+    if (rc) return rc;
+    if (global_batch < batch) return fail(CAE_ERR_ARG, "global_batch < batch");
+    StepArgs a{which, perm, batch, global_batch, true, true, nullptr, nullptr, true};
+    return run_op(e, OP_FWDBWD, a, true);
+}
+
+int cae_adam_step(cae_engine* e) {
+    if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+    StepArgs a{0, nullptr, 0, 0, false, false, nullptr, nullptr, false};
+    return run_op(e, OP_ADAM, a, true);
+}
+
+int cae_eval_step(cae_engine* e, int which, const int32_t* perm, int batch) {
+    int rc = check_ready(e, which, batch, true);
+    if (rc) return rc;
+    StepArgs a{which, perm, batch, batch, false, true, nullptr, nullptr, true};
+    return run_op(e, OP_EVAL, a, true);
+}
+
+int cae_score(cae_engine* e, const float* x, int batch, float* y) {
+    if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+    if (!x || !y) return fail(CAE_ERR_ARG, "cae_score: null pointer");
+    if (batch < 1 || batch > e->max_batch) return fail(CAE_ERR_ARG, "batch %d outside [1, %d]", batch, e->max_batch);
+    StepArgs a{0, nullptr, batch, batch, false, false, x, y, false};
+    return run_op(e, OP_EVAL, a, false);
+}
+
+int cae_read_losses(cae_engine* e, int first, int count, double* host_out) {
+    if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+    if (first < 0 || count < 0 || first + count > kLossSlots || !host_out) return fail(CAE_ERR_ARG, "bad loss range");
+    if (count == 0) return CAE_OK;
+    HIP_TRY(hipMemcpyAsync(host_out, e->losses() + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemsetAsync(e->losses() + first, 0, (size_t)count * sizeof(double), e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CAE_OK;
+}
+
+int cae_sync(cae_engine* e) {
+    if (!e) return fail(CAE_ERR_ARG, "null engine");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CAE_OK;
+}
+
+int64_t cae_debug_read(cae_engine* e, const char* what, int index, void* host_out, int64_t cap) {
+    if (!e || !e->ws || !what || !host_out) return fail(CAE_ERR_ARG, "cae_debug_read: bad argument");
+    const void* src = nullptr;
+    int64_t n = 0, esz = 4;
+    const int64_t mb = e->max_batch;
+    const std::string w(what);
+    const int n_enc = (int)e->enc.size(), n_dec = (int)e->dec.size();
+    auto conv_at = [&](int i) -> const ConvLayer* {
+        if (i < 0) return nullptr;
+        if (i < n_enc) return &e->enc[i];
+        if (i < n_enc + n_dec - 1) return &e->dec[i - n_enc];
+        return nullptr;
+    };
+    if (w == "act" || w == "grad") {
+        const ConvLayer* L = conv_at(index);
+        if (!L) return fail(CAE_ERR_ARG, "layer index out of range");
+        src = e->ws + (w == "act" ? L->act_off : L->grad_off);
+        n = mb * L->out_elems();
+    } else if (w == "glast") {
+        src = e->ws + e->off_glast;
+        n = mb * e->dec.back().out_elems();
+    } else if (w == "latent") {
+        src = e->ws + e->fc[1].act_off;
+        n = mb * e->fc[1].nout;
+    } else if (w == "fc") {
+        if (index < 0 || index > 3) return fail(CAE_ERR_ARG, "fc index out of range");
+        src = e->ws + e->fc[index].act_off;
+        n = mb * e->fc[index].nout;
+    } else if (w == "fcgrad") {
+        if (index < 0 || index > 3) return fail(CAE_ERR_ARG, "fc index out of range");
+        src = e->ws + e->fc[index].grad_off;
+        n = mb * e->fc[index].nout;
+    } else if (w == "grad_acc") {
+        src = e->gradacc();
+        n = e->n_param;
+        esz = 8;
+    } else if (w == "bn_stats") {
+        if (index < 0 || index >= e->n_bn) return fail(CAE_ERR_ARG, "bn index out of range");
+        src = e->bn_stats(index);
+        n = (int64_t)e->bn_channels[index] * 4;
+        esz = 8;
+    } else {
+        return fail(CAE_ERR_ARG, "unknown tensor '%s'", what);
+    }
+    if (n > cap) n = cap;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(host_out, src, (size_t)(n * esz), hipMemcpyDeviceToHost));
+    return n;
+}
+
+// ---- loader -------------------------------------------------------------------------------------
+
+int cae_scan_f32(const float* x, int64_t n, void* hip_stream, double* out3) {
+    if (!x || n < 1 || !out3) return fail(CAE_ERR_ARG, "cae_scan_f32: bad argument");
+    hipStream_t s = (hipStream_t)hip_stream;
+    int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    double* part = nullptr;
+    HIP_TRY(hipMalloc(&part, (size_t)blocks * 3 * sizeof(double)));
+    hipLaunchKernelGGL(k_scan, dim3(blocks), dim3(256), 0, s, x, (long long)n, part);
+    std::vector<double> host((size_t)blocks * 3);
+    hipError_t ce = hipMemcpyAsync(host.data(), part, host.size() * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(s);
+    (void)hipFree(part);
+    if (ce != hipSuccess) return fail(CAE_ERR_HIP, "cae_scan_f32: %s", hipGetErrorString(ce));
+    double cnt = 0, lo = INFINITY, hi = -INFINITY;
+    for (int i = 0; i < blocks; i++) {
+        cnt += host[3 * i];
+        lo = std::fmin(lo, host[3 * i + 1]);
+        hi = std::fmax(hi, host[3 * i + 2]);
+    }
+    out3[0] = cnt;
+    out3[1] = lo;
+    out3[2] = hi;
+    return CAE_OK;
+}
+
+int cae_normalise_pack(const float* src, int64_t n, int c_src, int64_t hw, float* dst, int c_dst, int c_off,
+                       float vmin, float range, int enable, void* hip_stream) {
+    if (!src || !dst || n < 1 || c_src < 1 || hw < 1 || c_off < 0 || c_off + c_src > c_dst)
+        return fail(CAE_ERR_ARG, "cae_normalise_pack: bad argument");
+    const long long total = (long long)n * c_src * hw;
+    int blocks = (int)((total + 256 * 8 - 1) / (256 * 8));
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_normalise_pack, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream, src, total, c_src,
+                       (long long)hw, dst, c_dst, c_off, vmin, range, enable);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_denormalise_f64(const float* y, int64_t n, double vmin, double range, double* out, void* hip_stream) {
+    if (!y || !out || n < 1) return fail(CAE_ERR_ARG, "cae_denormalise_f64: bad argument");
+    int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_denorm_f64, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream, y, (long long)n, vmin, range, out);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,599 @@
+// kernels_generic.h — shape-generic gfx950 kernels for every op of the ConvAE step.
+//
+// These are the fallback / reference-on-device kernels: any kernel size, stride, channel
+// count, output_padding.  One thread per output element, BatchNorm + ReLU folded into the
+// operand load of the consumer, all cross-block reductions through fp64 atomics.  The
+// specialised kernels in kernels_s2.h replace them for the stride-2 layers that carry the
+// traffic; both are checked against the CPU oracle.
+//
+// Every conv-like op is one of three primitives on a "small" map S (B,Cs,Hs,Ws), a "big" map
+// L (B,Cl,Hl,Wl) and weights w[cs][cl][ky][kx]  (that IS PyTorch's layout for both
+// Conv2d (Cout,Cin,kh,kw) with S = output and ConvTranspose2d (Cin,Cout,kh,kw) with S = input):
+//   down : S[cs][y][x]   = sum_cl,ky,kx L[cl][y*s+ky][x*s+kx] * w      (Conv2d fwd, ConvT dgrad)
+//   up   : L[cl][Y][X]   = sum_cs,ky,kx S[cs][(Y-ky)/s][(X-kx)/s] * w  (ConvT fwd, Conv2d dgrad)
+//   wgrad: dw[cs][cl][ky][kx] = sum_b,y,x S[cs][y][x] * L[cl][y*s+ky][x*s+kx]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cae {
+
+struct StepState {
+    long long batch_start;  // first position in the permutation of the current batch
+    int loss_slot;          // where this step's loss is accumulated
+    int adam_step;          // completed optimiser steps
+};
+
+// How a tensor that is READ relates to BatchNorm.
+enum BnMode : int {
+    BN_NONE = 0,     // identity
+    BN_BATCH = 1,    // activation a = relu((y-mean)*scale+beta), mean/var from this step's sums
+    BN_RUNNING = 2,  // same with running statistics (eval)
+    BN_SAVED = 3,    // same with the mean/invstd the forward pass saved (backward reads)
+    BN_BWD = 4       // gradient wrt the raw conv output: k1*g - k2 - (y-mean)*k3
+};
+
+struct BnDesc {
+    int mode;
+    int C;
+    const double* stats;  // [C][4]: sum y, sum y^2, sum g, sum g*xhat
+    const float* gamma;
+    const float* beta;
+    float* rmean;
+    float* rvar;
+    float* saved;  // [C][2]: mean, invstd
+    double count;  // elements per channel (global count under SyncBN)
+    float momentum;
+    float eps;
+    int update;    // BN_BATCH: this consumer also updates running stats and `saved`
+};
+
+// A tensor read through an optional per-channel transform.
+struct Src {
+    const float* p;    // data (for BN_BWD: the masked upstream gradient g)
+    const float* q;    // BN_BWD only: the raw forward output y
+    const int* perm;   // dataset gather: sample = perm[batch_start + b]   (nullptr: sample = b)
+    int use_cursor;    // add StepState.batch_start even when perm == nullptr
+    int C, H, W;
+};
+
+enum EpiKind : int { EPI_PLAIN = 0, EPI_STATS = 1, EPI_MASKSTATS = 2, EPI_SIGMSE = 3, EPI_SIGOUT = 4 };
+
+struct Epi {
+    int kind;
+    float* out;           // PLAIN/STATS: raw output; MASKSTATS: masked gradient; SIGMSE: dL/d(pre-sigmoid)
+    double* stats;        // STATS: [C][4] slots 0,1; MASKSTATS: slots 2,3
+    const float* yprev;   // MASKSTATS: raw forward output at the same element
+    const float* target;  // SIGMSE / SIGOUT(optional)
+    const int* perm;
+    int use_cursor;
+    double* losses;       // SIGMSE / SIGOUT: per-slot loss accumulators
+    float inv_count;      // 1 / (global_batch * C * H * W)
+    double* bias_acc;     // SIGMSE: gradient accumulator of the last layer's bias
+    float* yhat;          // SIGOUT: sigmoid output (may be nullptr when only the loss is wanted)
+};
+
+struct ConvGeom {
+    int B, Cs, Hs, Ws, Cl, Hl, Wl, kh, kw, s;
+};
+
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// sum of v over the block, valid in thread 0.  red: LDS scratch of >= blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; i++) t += red[i];
+    }
+    return t;
+}
+
+// Per-channel constants for a BnDesc into LDS.
+//   activation modes: {mean, gamma*invstd, beta, invstd}
+//   BN_BWD:           {mean, k1, k2, k3}  with  gy = k1*g - k2 - (y-mean)*k3
+__device__ __forceinline__ void bn_consts(const BnDesc& d, float4* out, bool designated) {
+    if (d.mode == BN_NONE) return;
+    for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+        float mean, invstd;
+        if (d.mode == BN_BATCH) {
+            const double s1 = d.stats[4 * c], s2 = d.stats[4 * c + 1];
+            const double m = s1 / d.count;
+            double var = s2 / d.count - m * m;
+            var = var < 0.0 ? 0.0 : var;
+            mean = (float)m;
+            invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+            if (designated && d.update) {
+                d.saved[2 * c] = mean;
+                d.saved[2 * c + 1] = invstd;
+                const double unb = d.count > 1.0 ? var * (d.count / (d.count - 1.0)) : var;
+                d.rmean[c] = (1.f - d.momentum) * d.rmean[c] + d.momentum * mean;
+                d.rvar[c] = (1.f - d.momentum) * d.rvar[c] + d.momentum * (float)unb;
+            }
+        } else if (d.mode == BN_RUNNING) {
+            mean = d.rmean[c];
+            invstd = 1.0f / sqrtf(d.rvar[c] + d.eps);
+        } else {
+            mean = d.saved[2 * c];
+            invstd = d.saved[2 * c + 1];
+        }
+        const float scale = d.gamma[c] * invstd;
+        if (d.mode == BN_BWD) {
+            const double dbeta = d.stats[4 * c + 2], dgamma = d.stats[4 * c + 3];
+            const float k2 = (float)((double)scale * dbeta / d.count);
+            const float k3 = (float)((double)scale * (double)invstd * dgamma / d.count);
+            out[c] = make_float4(mean, scale, k2, k3);
+        } else {
+            out[c] = make_float4(mean, scale, d.beta[c], invstd);
+        }
+    }
+}
+
+__device__ __forceinline__ float bn_apply(int mode, const float4 k, float v, float yraw) {
+    if (mode == BN_NONE) return v;
+    if (mode == BN_BWD) return k.y * v - k.z - (yraw - k.x) * k.w;
+    return fmaxf(0.f, fmaf(v - k.x, k.y, k.z));
+}
+
+__device__ __forceinline__ size_t sample_of(const int* perm, int use_cursor, const StepState* st, int b) {
+    if (perm) return (size_t)perm[st->batch_start + b];
+    if (use_cursor) return (size_t)(st->batch_start + b);
+    return (size_t)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared epilogue: thread-level part returns the two values to be block-reduced
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void epi_element(const Epi& e, const float4* ce, int c, size_t o, size_t tgt_off,
+                                             float acc, double& r1, double& r2) {
+    switch (e.kind) {
+        case EPI_PLAIN:
+            e.out[o] = acc;
+            break;
+        case EPI_STATS:
+            e.out[o] = acc;
+            r1 = (double)acc;
+            r2 = (double)acc * (double)acc;
+            break;
+        case EPI_MASKSTATS: {
+            const float4 k = ce[c];
+            const float yv = e.yprev[o];
+            const float d = yv - k.x;
+            const float a = fmaf(d, k.y, k.z);
+            const float g = a > 0.f ? acc : 0.f;
+            e.out[o] = g;
+            r1 = (double)g;
+            r2 = (double)g * (double)(d * k.w);
+            break;
+        }
+        case EPI_SIGMSE: {
+            const float yh = 1.0f / (1.0f + expf(-acc));
+            const float d = yh - e.target[tgt_off];
+            const float g = (2.0f * d * e.inv_count) * (yh * (1.0f - yh));
+            e.out[o] = g;
+            r1 = (double)d * (double)d * (double)e.inv_count;
+            r2 = (double)g;
+            break;
+        }
+        case EPI_SIGOUT: {
+            const float yh = 1.0f / (1.0f + expf(-acc));
+            if (e.yhat) e.yhat[o] = yh;
+            if (e.target) {
+                const float d = yh - e.target[tgt_off];
+                r1 = (double)d * (double)d * (double)e.inv_count;
+            }
+            break;
+        }
+    }
+}
+
+__device__ __forceinline__ void epi_block(const Epi& e, int c, const StepState* st, double r1, double r2,
+                                          double* red) {
+    if (e.kind == EPI_PLAIN) return;
+    if (e.kind == EPI_SIGOUT && !e.target) return;
+    const double t1 = block_sum(r1, red);
+    const double t2 = (e.kind == EPI_SIGOUT) ? 0.0 : block_sum(r2, red);
+    if (threadIdx.x == 0) {
+        if (e.kind == EPI_STATS) {
+            atomicAdd(&e.stats[4 * c + 0], t1);
+            atomicAdd(&e.stats[4 * c + 1], t2);
+        } else if (e.kind == EPI_MASKSTATS) {
+            atomicAdd(&e.stats[4 * c + 2], t1);
+            atomicAdd(&e.stats[4 * c + 3], t2);
+        } else if (e.kind == EPI_SIGMSE) {
+            atomicAdd(&e.losses[st->loss_slot], t1);
+            atomicAdd(&e.bias_acc[c], t2);
+        } else {
+            atomicAdd(&e.losses[st->loss_slot], t1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// down: S[b][cs][y][x] = bias[cs] + sum_cl,ky,kx T(L[b][cl][y*s+ky][x*s+kx]) * w[cs][cl][ky][kx]
+// grid (ceil(B*Hs*Ws/256), Cs), block 256, dynamic LDS (Cl + Cs) float4 + 4 doubles
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_down(ConvGeom g, Src big, BnDesc bnb, const float* __restrict__ w,
+                                               const float* __restrict__ bias, Epi e, BnDesc bne,
+                                               const StepState* __restrict__ st) {
+    extern __shared__ double lds_d[];
+    double* red = lds_d;
+    float4* cb = reinterpret_cast<float4*>(lds_d + 4);
+    float4* ce = cb + g.Cl;
+    const bool designated = blockIdx.x == 0 && blockIdx.y == 0;
+    bn_consts(bnb, cb, designated);
+    bn_consts(bne, ce, false);
+    __syncthreads();
+
+    const int cs = blockIdx.y;
+    const int hw = g.Hs * g.Ws;
+    const int n = g.B * hw;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    double r1 = 0, r2 = 0;
+    if (idx < n) {
+        const int b = idx / hw, r = idx - b * hw;
+        const int y = r / g.Ws, x = r - y * g.Ws;
+        const size_t sb = sample_of(big.perm, big.use_cursor, st, b);
+        float acc = bias ? bias[cs] : 0.f;
+        for (int cl = 0; cl < g.Cl; cl++) {
+            const float* wp = w + (size_t)(cs * g.Cl + cl) * g.kh * g.kw;
+            const size_t base = (sb * g.Cl + cl) * (size_t)g.Hl * g.Wl;
+            const float4 k = bnb.mode ? cb[cl] : make_float4(0, 0, 0, 0);
+            for (int ky = 0; ky < g.kh; ky++) {
+                const size_t row = base + (size_t)(y * g.s + ky) * g.Wl + (size_t)x * g.s;
+                for (int kx = 0; kx < g.kw; kx++) {
+                    const float v = big.p[row + kx];
+                    const float yr = bnb.mode == BN_BWD ? big.q[row + kx] : 0.f;
+                    acc = fmaf(bn_apply(bnb.mode, k, v, yr), wp[ky * g.kw + kx], acc);
+                }
+            }
+        }
+        const size_t o = ((size_t)(b * g.Cs + cs) * g.Hs + y) * g.Ws + x;
+        epi_element(e, ce, cs, o, 0, acc, r1, r2);
+    }
+    epi_block(e, cs, st, r1, r2, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// up: L[b][cl][Y][X] = bias[cl] + sum_cs sum_{ky = Y mod s (s) , kx = X mod s (s)}
+//                                   T(S[b][cs][(Y-ky)/s][(X-kx)/s]) * w[cs][cl][ky][kx]
+// grid (ceil(B*Hl*Wl/256), Cl)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_up(ConvGeom g, Src small, BnDesc bns, const float* __restrict__ w,
+                                             const float* __restrict__ bias, Epi e, BnDesc bne,
+                                             const StepState* __restrict__ st) {
+    extern __shared__ double lds_d[];
+    double* red = lds_d;
+    float4* cs4 = reinterpret_cast<float4*>(lds_d + 4);
+    float4* ce = cs4 + g.Cs;
+    const bool designated = blockIdx.x == 0 && blockIdx.y == 0;
+    bn_consts(bns, cs4, designated);
+    bn_consts(bne, ce, false);
+    __syncthreads();
+
+    const int cl = blockIdx.y;
+    const int hw = g.Hl * g.Wl;
+    const int n = g.B * hw;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    double r1 = 0, r2 = 0;
+    if (idx < n) {
+        const int b = idx / hw, r = idx - b * hw;
+        const int Y = r / g.Wl, X = r - Y * g.Wl;
+        const size_t sb = sample_of(small.perm, small.use_cursor, st, b);
+        float acc = bias ? bias[cl] : 0.f;
+        const int ky0 = Y % g.s, kx0 = X % g.s;
+        for (int cs = 0; cs < g.Cs; cs++) {
+            const float* wp = w + (size_t)(cs * g.Cl + cl) * g.kh * g.kw;
+            const size_t base = (sb * g.Cs + cs) * (size_t)g.Hs * g.Ws;
+            const float4 k = bns.mode ? cs4[cs] : make_float4(0, 0, 0, 0);
+            for (int ky = ky0; ky < g.kh && ky <= Y; ky += g.s) {
+                const int y = (Y - ky) / g.s;
+                if (y >= g.Hs) continue;
+                for (int kx = kx0; kx < g.kw && kx <= X; kx += g.s) {
+                    const int x = (X - kx) / g.s;
+                    if (x >= g.Ws) continue;
+                    const size_t off = base + (size_t)y * g.Ws + x;
+                    const float v = small.p[off];
+                    const float yr = bns.mode == BN_BWD ? small.q[off] : 0.f;
+                    acc = fmaf(bn_apply(bns.mode, k, v, yr), wp[ky * g.kw + kx], acc);
+                }
+            }
+        }
+        const size_t o = ((size_t)(b * g.Cl + cl) * g.Hl + Y) * g.Wl + X;
+        size_t tgt = 0;
+        if (e.kind >= EPI_SIGMSE && e.target) {
+            const size_t tb = sample_of(e.perm, e.use_cursor, st, b);
+            tgt = ((tb * g.Cl + cl) * (size_t)g.Hl + Y) * g.Wl + X;
+        }
+        epi_element(e, ce, cl, o, tgt, acc, r1, r2);
+    }
+    epi_block(e, cl, st, r1, r2, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad: acc[cs][cl][ky][kx] += sum_{b,y,x} Ts(S[b][cs][y][x]) * Tl(L[b][cl][y*s+ky][x*s+kx])
+// grid (Cs*Cl*kh*kw, nsplit); each block covers `ppb` positions of (b,y,x).
+// The designated block also publishes the BatchNorm parameter gradients of the layer whose
+// backward this is (dgamma = sum g*xhat, dbeta = sum g), taken from the fp64 stat sums.
+// ---------------------------------------------------------------------------------------------
+struct BnGradOut {
+    const double* stats;  // [C][4] of the BN that follows this layer, or nullptr
+    double* gamma_acc;
+    double* beta_acc;
+    int C;
+    double scale;  // 1/nranks under SyncBN (the sums are already global), else 1
+};
+
+__global__ void __launch_bounds__(256) k_wgrad(ConvGeom g, Src small, BnDesc bns, Src big, BnDesc bnb,
+                                                double* __restrict__ acc, int ppb, BnGradOut bg,
+                                                const StepState* __restrict__ st) {
+    extern __shared__ double lds_d[];
+    double* red = lds_d;
+    float4* cs4 = reinterpret_cast<float4*>(lds_d + 4);
+    float4* cb = cs4 + g.Cs;
+    bn_consts(bns, cs4, false);
+    bn_consts(bnb, cb, false);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && bg.stats) {
+        for (int c = threadIdx.x; c < bg.C; c += blockDim.x) {
+            bg.beta_acc[c] = bg.stats[4 * c + 2] * bg.scale;
+            bg.gamma_acc[c] = bg.stats[4 * c + 3] * bg.scale;
+        }
+    }
+    __syncthreads();
+
+    int widx = blockIdx.x;
+    const int kx = widx % g.kw;
+    widx /= g.kw;
+    const int ky = widx % g.kh;
+    widx /= g.kh;
+    const int cl = widx % g.Cl;
+    const int cs = widx / g.Cl;
+    const float4 ks = bns.mode ? cs4[cs] : make_float4(0, 0, 0, 0);
+    const float4 kb = bnb.mode ? cb[cl] : make_float4(0, 0, 0, 0);
+
+    const int hw = g.Hs * g.Ws;
+    const long long n = (long long)g.B * hw;
+    const long long p0 = (long long)blockIdx.y * ppb;
+    long long p1 = p0 + ppb;
+    if (p1 > n) p1 = n;
+    float sum = 0.f;
+    for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int b = (int)(p / hw), r = (int)(p - (long long)b * hw);
+        const int y = r / g.Ws, x = r - y * g.Ws;
+        const size_t ss = sample_of(small.perm, small.use_cursor, st, b);
+        const size_t sl = sample_of(big.perm, big.use_cursor, st, b);
+        const size_t so = ((ss * g.Cs + cs) * (size_t)g.Hs + y) * g.Ws + x;
+        const size_t lo = ((sl * g.Cl + cl) * (size_t)g.Hl + (size_t)(y * g.s + ky)) * g.Wl + (size_t)x * g.s + kx;
+        const float sv = bn_apply(bns.mode, ks, small.p[so], bns.mode == BN_BWD ? small.q[so] : 0.f);
+        const float lv = bn_apply(bnb.mode, kb, big.p[lo], bnb.mode == BN_BWD ? big.q[lo] : 0.f);
+        sum = fmaf(sv, lv, sum);
+    }
+    const double t = block_sum((double)sum, red);
+    if (threadIdx.x == 0) atomicAdd(&acc[blockIdx.x], t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Linear layers (encoder.py:54-58, decoder.py:31-35), weight W[out][in]
+// ---------------------------------------------------------------------------------------------
+
+// out[b][o] = act(bias[o] + sum_i T(in[b][i]) * W[o][i]);  T = BN+ReLU per channel i/hw or identity
+__global__ void __launch_bounds__(256) k_lin_fwd(int B, int nin, int nout, const float* __restrict__ in,
+                                                  BnDesc bni, int hw, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, int relu,
+                                                  float* __restrict__ out) {
+    extern __shared__ double lds_d[];
+    float4* ci = reinterpret_cast<float4*>(lds_d + 4);
+    bn_consts(bni, ci, blockIdx.x == 0);
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * nout) return;
+    const int b = idx / nout, o = idx - b * nout;
+    const float* ip = in + (size_t)b * nin;
+    const float* wp = W + (size_t)o * nin;
+    float acc = bias[o];
+    if (bni.mode) {
+        for (int i = 0; i < nin; i++) acc = fmaf(bn_apply(bni.mode, ci[i / hw], ip[i], 0.f), wp[i], acc);
+    } else {
+        for (int i = 0; i < nin; i++) acc = fmaf(ip[i], wp[i], acc);
+    }
+    out[idx] = relu ? fmaxf(acc, 0.f) : acc;
+}
+
+// gin[b][i] = M( sum_o gout[b][o] * W[o][i] )
+//   epi 0: M = identity; 1: M = mask by hin[b][i] > 0 (ReLU of the producing Linear);
+//   epi 2: M = mask by BN+ReLU of yprev + D1/D2 sums (grid.y = channel, i = c*hw + r)
+__global__ void __launch_bounds__(256) k_lin_dgrad(int B, int nin, int nout, const float* __restrict__ gout,
+                                                    const float* __restrict__ W, int epi,
+                                                    const float* __restrict__ hin, BnDesc bne, int hw,
+                                                    double* stats, float* __restrict__ gin) {
+    extern __shared__ double lds_d[];
+    double* red = lds_d;
+    float4* ce = reinterpret_cast<float4*>(lds_d + 4);
+    bn_consts(bne, ce, false);
+    __syncthreads();
+    double r1 = 0, r2 = 0;
+    if (epi != 2) {
+        const int idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx < B * nin) {
+            const int b = idx / nin, i = idx - b * nin;
+            const float* gp = gout + (size_t)b * nout;
+            float acc = 0.f;
+            for (int o = 0; o < nout; o++) acc = fmaf(gp[o], W[(size_t)o * nin + i], acc);
+            if (epi == 1) acc = hin[idx] > 0.f ? acc : 0.f;
+            gin[idx] = acc;
+        }
+        return;
+    }
+    const int c = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < B * hw) {
+        const int b = idx / hw, r = idx - b * hw;
+        const int i = c * hw + r;
+        const float* gp = gout + (size_t)b * nout;
+        float acc = 0.f;
+        for (int o = 0; o < nout; o++) acc = fmaf(gp[o], W[(size_t)o * nin + i], acc);
+        const size_t off = (size_t)b * nin + i;
+        const float4 k = ce[c];
+        const float d = hin[off] - k.x;
+        const float a = fmaf(d, k.y, k.z);
+        const float gm = a > 0.f ? acc : 0.f;
+        gin[off] = gm;
+        r1 = (double)gm;
+        r2 = (double)gm * (double)(d * k.w);
+    }
+    const double t1 = block_sum(r1, red);
+    const double t2 = block_sum(r2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[4 * c + 2], t1);
+        atomicAdd(&stats[4 * c + 3], t2);
+    }
+}
+
+// accW[o][i] = sum_b gout[b][o] * T(in[b][i]);  accB[o] = sum_b gout[b][o]
+__global__ void __launch_bounds__(256) k_lin_wgrad(int B, int nin, int nout, const float* __restrict__ gout,
+                                                    const float* __restrict__ in, BnDesc bni, int hw,
+                                                    double* __restrict__ accW, double* __restrict__ accB) {
+    extern __shared__ double lds_d[];
+    float4* ci = reinterpret_cast<float4*>(lds_d + 4);
+    bn_consts(bni, ci, false);
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nout * nin) return;
+    const int o = idx / nin, i = idx - o * nin;
+    const float4 k = bni.mode ? ci[i / hw] : make_float4(0, 0, 0, 0);
+    float sum = 0.f, bsum = 0.f;
+    for (int b = 0; b < B; b++) {
+        const float gv = gout[(size_t)b * nout + o];
+        sum = fmaf(gv, bn_apply(bni.mode, k, in[(size_t)b * nin + i], 0.f), sum);
+        bsum += gv;
+    }
+    accW[idx] = (double)sum;
+    if (i == 0) accB[o] = (double)bsum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimiser + bookkeeping
+// ---------------------------------------------------------------------------------------------
+struct Hyper {
+    double lr, beta1, beta2, eps, wd;
+};
+
+// torch.optim.Adam single-tensor update (L2 weight decay added to the gradient), element-wise
+// over the flat arena.  Gradient source: fp64 accumulator (fused path) or fp32 arena (DP path).
+__global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p, const double* __restrict__ acc,
+                                               const float* __restrict__ g32, float* __restrict__ m,
+                                               float* __restrict__ v, Hyper h, const StepState* __restrict__ st) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int t = st->adam_step + 1;
+    const double bc1 = 1.0 - pow(h.beta1, (double)t);
+    const double bc2 = 1.0 - pow(h.beta2, (double)t);
+    const float step_size = (float)(h.lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float b1 = (float)h.beta1, b2 = (float)h.beta2;
+    float g = acc ? (float)acc[i] : g32[i];
+    const float w = p[i];
+    if (h.wd != 0.0) g = fmaf((float)h.wd, w, g);
+    float mi = m[i], vi = v[i];
+    mi = mi + (g - mi) * (1.0f - b1);
+    vi = vi * b2 + ((1.0f - b2) * g) * g;
+    const float denom = sqrtf(vi) / bc2_sqrt + (float)h.eps;
+    p[i] = w - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+}
+
+__global__ void k_acc_to_f32(long long n, const double* __restrict__ acc, float* __restrict__ g) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) g[i] = (float)acc[i];
+}
+
+__global__ void k_set_state(StepState* st, long long batch_start, int loss_slot, int set_cursor, int adam_step,
+                            int set_adam) {
+    if (set_cursor) {
+        st->batch_start = batch_start;
+        st->loss_slot = loss_slot;
+    }
+    if (set_adam) st->adam_step = adam_step;
+}
+
+__global__ void k_advance(StepState* st, int batch, int slot_inc, int adam_inc) {
+    st->batch_start += batch;
+    st->loss_slot += slot_inc;
+    st->adam_step += adam_inc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// loader kernels (ds_dataset.py)
+// ---------------------------------------------------------------------------------------------
+
+// per-block partial {nan count, min, max}; out [gridDim.x][3] doubles
+__global__ void __launch_bounds__(256) k_scan(const float* __restrict__ x, long long n, double* __restrict__ out) {
+    __shared__ double red[3][4];
+    double cnt = 0;
+    float lo = INFINITY, hi = -INFINITY;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        if (v != v) {
+            cnt += 1;
+        } else {
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off, 64);
+        lo = fminf(lo, __shfl_down(lo, off, 64));
+        hi = fmaxf(hi, __shfl_down(hi, off, 64));
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wv] = cnt;
+        red[1][wv] = lo;
+        red[2][wv] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0, l = INFINITY, h = -INFINITY;
+        for (int i = 0; i < 4; i++) {
+            c += red[0][i];
+            l = fmin(l, red[1][i]);
+            h = fmax(h, red[2][i]);
+        }
+        out[3 * blockIdx.x + 0] = c;
+        out[3 * blockIdx.x + 1] = l;
+        out[3 * blockIdx.x + 2] = h;
+    }
+}
+
+// dst[i][c_off + c][:] = (src[i][c][:] - vmin) / range   (two correctly rounded fp32 ops, as numpy)
+__global__ void __launch_bounds__(256) k_normalise_pack(const float* __restrict__ src, long long total, int c_src,
+                                                         long long hw, float* __restrict__ dst, int c_dst, int c_off,
+                                                         float vmin, float range, int enable) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long per = (long long)c_src * hw;
+        const long long s = i / per, r = i - s * per;
+        float v = src[i];
+        if (enable) v = (range == 0.f) ? 0.f : __fdiv_rn(__fsub_rn(v, vmin), range);
+        dst[(s * c_dst + c_off) * hw + r] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_denorm_f64(const float* __restrict__ y, long long n, double vmin, double range,
+                                                     double* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = __dadd_rn(vmin, __dmul_rn((double)y[i], range));
+}
+
+}  // namespace cae

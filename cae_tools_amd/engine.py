@@ -1,0 +1,338 @@
+"""HipEngine — Python owner of one libcae_hip engine and of the device memory it works on.
+
+torch is used here as a container only: flat CUDA tensors for the parameter / gradient / Adam /
+running-stat arenas and the workspace, a side stream, and (in dp.py) torch.distributed.  Every
+FLOP of the model runs in the HIP kernels behind include/cae_hip.h.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CaeError, LayerSpecC, TensorInfoC, check
+
+TRAIN, TEST = 0, 1
+
+
+def _spec_layers(spec):
+    """accept a ModelSpec-like object or its JSON dict; return two lists of plain dicts"""
+    if hasattr(spec, "save"):
+        spec = spec.save()
+    return spec["input_layers"], spec["output_layers"]
+
+
+def _to_c(layers):
+    arr = (LayerSpecC * len(layers))()
+    for i, l in enumerate(layers):
+        k = l["kernel_size"]
+        (kh, kw) = (int(k[0]), int(k[1])) if isinstance(k, (list, tuple)) else (int(k), int(k))
+        (ic, ih, iw) = l["input_dimensions"]
+        (oc, oh, ow) = l["output_dimensions"]
+        arr[i] = LayerSpecC(ic, ih, iw, oc, oh, ow, kh, kw, int(l["stride"]), int(l.get("output_padding", 0)))
+    return arr
+
+
+class EnginePlan:
+    """Geometry-only view of an engine (no GPU needed): tensor table, arena and workspace sizes."""
+
+    def __init__(self, spec, fc_size, latent_size, max_batch):
+        self.lib = _lib.load()
+        (enc, dec) = _spec_layers(spec)
+        self.enc_layers, self.dec_layers = enc, dec
+        self.fc_size, self.latent_size, self.max_batch = int(fc_size), int(latent_size), int(max_batch)
+        handle = C.c_void_p()
+        check(self.lib.cae_engine_create(_to_c(enc), len(enc), _to_c(dec), len(dec), self.fc_size,
+                                         self.latent_size, self.max_batch, C.byref(handle)))
+        self.handle = handle
+        self.n_param = int(self.lib.cae_param_count(handle))
+        self.n_buffer = int(self.lib.cae_buffer_count(handle))
+        self.workspace_bytes = int(self.lib.cae_workspace_bytes(handle))
+        self.tensors = OrderedDict()
+        info = TensorInfoC()
+        for i in range(self.lib.cae_tensor_count(handle)):
+            check(self.lib.cae_tensor_info(handle, i, C.byref(info)))
+            shape = tuple(int(info.shape[d]) for d in range(info.ndim))
+            self.tensors[info.name.decode()] = (int(info.arena), int(info.offset), int(info.numel), shape)
+        self.in_shape = tuple(enc[0]["input_dimensions"])
+        self.out_shape = tuple(dec[-1]["output_dimensions"])
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.cae_engine_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bn_prefixes(self):
+        """state_dict prefixes ("enc/encoder_cnn.1") of the BatchNorm layers, in order"""
+        return [n[: -len(".running_mean")] for n in self.tensors if n.endswith(".running_mean")]
+
+
+class HipEngine(EnginePlan):
+
+    def __init__(self, spec, fc_size, latent_size, max_batch, device=None, graph=True):
+        if not torch.cuda.is_available():
+            raise CaeError("cae_tools_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+        super().__init__(spec, fc_size, latent_size, max_batch)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.Stream()
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(self.n_param, **f32)
+        self.grads = torch.zeros(self.n_param, **f32)
+        self.exp_avg = torch.zeros(self.n_param, **f32)
+        self.exp_avg_sq = torch.zeros(self.n_param, **f32)
+        self.buffers = torch.zeros(max(self.n_buffer, 4), **f32)
+        self.workspace = torch.zeros(self.workspace_bytes + 256, dtype=torch.uint8, device=self.device)
+        ws_ptr = (self.workspace.data_ptr() + 255) // 256 * 256
+        check(self.lib.cae_bind(self.handle, self.params.data_ptr(), self.grads.data_ptr(),
+                                self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.buffers.data_ptr(),
+                                ws_ptr, self.workspace_bytes))
+        check(self.lib.cae_set_stream(self.handle, self.stream.cuda_stream))
+        check(self.lib.cae_set_graph_mode(self.handle, 1 if graph else 0))
+        torch.cuda.synchronize(self.device)
+        self.num_batches_tracked = 0
+        self.adam_steps = 0
+        self._datasets = {}
+        self._keep = []
+        self.loss_slots = int(self.lib.cae_loss_slots(self.handle))
+        self._slot = 0
+
+    # ---- parameters ------------------------------------------------------------------------
+    def _arena(self, arena):
+        return self.params if arena == 0 else self.buffers
+
+    def view(self, name):
+        """torch view (device) of a named tensor, e.g. 'dec/decoder_conv.0.weight'"""
+        (arena, off, numel, shape) = self.tensors[name]
+        return self._arena(arena)[off:off + numel].view(shape)
+
+    def grad_view(self, name):
+        (arena, off, numel, shape) = self.tensors[name]
+        assert arena == 0
+        return self.grads[off:off + numel].view(shape)
+
+    def load_state(self, enc_state, dec_state):
+        """copy reference-format state dicts (encoder.weights / decoder.weights) into the arenas"""
+        self.sync()
+        nbt = None
+        for prefix, sd in (("enc/", enc_state), ("dec/", dec_state)):
+            for k, v in sd.items():
+                if k.endswith("num_batches_tracked"):
+                    nbt = int(np.asarray(v)) if nbt is None else nbt
+                    continue
+                name = prefix + k
+                if name not in self.tensors:
+                    raise CaeError(f"unexpected tensor '{k}' for this model geometry")
+                t = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v).to(torch.float32)
+                dst = self.view(name)
+                if tuple(t.shape) != tuple(dst.shape):
+                    raise CaeError(f"shape mismatch for '{k}': {tuple(t.shape)} vs {tuple(dst.shape)}")
+                dst.copy_(t.to(self.device))
+        missing = [n for n in self.tensors if (n[4:] not in (enc_state if n.startswith("enc/") else dec_state))]
+        if missing:
+            raise CaeError(f"state dict is missing {missing[:3]}...")
+        if nbt is not None:
+            self.num_batches_tracked = nbt
+        torch.cuda.synchronize(self.device)
+
+    def export_state(self):
+        """(encoder_state, decoder_state) as CPU tensors under the reference's state_dict keys and
+        order, including num_batches_tracked"""
+        self.sync()
+        enc, dec = OrderedDict(), OrderedDict()
+        for name in self.tensors:
+            side = enc if name.startswith("enc/") else dec
+            side[name[4:]] = self.view(name).detach().cpu().clone()
+            if name.endswith(".running_var"):
+                side[name[4:-len("running_var")] + "num_batches_tracked"] = torch.tensor(
+                    self.num_batches_tracked, dtype=torch.int64)
+        # state_dict order of nn.BatchNorm2d: weight, bias, running_mean, running_var, num_batches_tracked
+        return self._ordered(enc), self._ordered(dec)
+
+    @staticmethod
+    def _ordered(sd):
+        order = {"weight": 0, "bias": 1, "running_mean": 2, "running_var": 3, "num_batches_tracked": 4}
+        groups = OrderedDict()
+        for k in sd:
+            groups.setdefault(k.rsplit(".", 1)[0], []).append(k)
+        out = OrderedDict()
+        for g, keys in groups.items():
+            for k in sorted(keys, key=lambda s: order[s.rsplit(".", 1)[1]]):
+                out[k] = sd[k]
+        return out
+
+    def reset_optimizer(self):
+        """a fresh torch.optim.Adam (conv_ae_model.py:310 re-creates it on every train())"""
+        self.sync()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.adam_steps = 0
+        torch.cuda.synchronize(self.device)
+        check(self.lib.cae_set_adam_step(self.handle, 0))
+
+    def set_hyper(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5):
+        check(self.lib.cae_set_hyper(self.handle, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                     float(weight_decay)))
+
+    # ---- data ------------------------------------------------------------------------------
+    def set_dataset(self, which, x, t=None):
+        """x (N,C,H,W) / t (N,C,H,W): fp32 CUDA tensors, already normalised; kept alive here"""
+        for name, a, shp in (("x", x, self.in_shape), ("t", t, self.out_shape)):
+            if a is None:
+                continue
+            if a.dtype != torch.float32 or not a.is_cuda or not a.is_contiguous():
+                raise CaeError(f"dataset {name} must be a contiguous fp32 CUDA tensor")
+            if tuple(a.shape[1:]) != tuple(shp):
+                raise CaeError(f"dataset {name} has sample shape {tuple(a.shape[1:])}, model expects {tuple(shp)}")
+        self.sync()
+        torch.cuda.synchronize(self.device)
+        self._datasets[which] = (x, t)
+        check(self.lib.cae_set_dataset(self.handle, which, x.data_ptr(), t.data_ptr() if t is not None else None,
+                                       int(x.shape[0])))
+
+    def upload_perm(self, perm):
+        """int32 device copy of a sample permutation / index list"""
+        p = torch.as_tensor(np.asarray(perm, dtype=np.int32)).to(self.device)
+        torch.cuda.synchronize(self.device)
+        self._keep.append(p)
+        if len(self._keep) > 64:
+            self.sync()
+            self._keep = self._keep[-8:]
+        return p
+
+    # ---- steps -----------------------------------------------------------------------------
+    def _claim_slots(self, n):
+        if n > self.loss_slots:
+            raise CaeError(f"{n} steps between loss reads exceeds {self.loss_slots} slots")
+        if self._slot + n > self.loss_slots:
+            self._slot = 0
+        first = self._slot
+        self._slot += n
+        return first
+
+    def _read_losses(self, first, n):
+        out = (C.c_double * n)()
+        check(self.lib.cae_read_losses(self.handle, first, n, out))
+        return [float(v) for v in out]
+
+    def run_batches(self, which, perm_dev, n, batch_size, train=True):
+        """One pass over perm[0:n] in batches of batch_size (last one partial, drop_last=False as in
+        conv_ae_model.py:291-292).  Returns the per-batch mean losses
+        (__train_epoch :185-203 / __test_epoch :205-221)."""
+        nb = (n + batch_size - 1) // batch_size
+        first = self._claim_slots(nb)
+        ptr = perm_dev.data_ptr() if perm_dev is not None else None
+        check(self.lib.cae_set_cursor(self.handle, 0, first))
+        fn = self.lib.cae_train_step if train else self.lib.cae_eval_step
+        for b in range(nb):
+            size = min(batch_size, n - b * batch_size)
+            check(fn(self.handle, which, ptr, size))
+        if train:
+            self.num_batches_tracked += nb
+            self.adam_steps += nb
+        return self._read_losses(first, nb)
+
+    def train_step(self, which, perm_dev, start, size):
+        """a single training step on perm[start:start+size]; returns its loss (blocking)"""
+        first = self._claim_slots(1)
+        check(self.lib.cae_set_cursor(self.handle, int(start), first))
+        check(self.lib.cae_train_step(self.handle, which, perm_dev.data_ptr() if perm_dev is not None else None,
+                                      int(size)))
+        self.num_batches_tracked += 1
+        self.adam_steps += 1
+        return self._read_losses(first, 1)[0]
+
+    def enqueue_train_steps(self, which, perm_dev, n, batch_size, slot_first):
+        """bench helper: enqueue one pass without reading anything back"""
+        nb = (n + batch_size - 1) // batch_size
+        ptr = perm_dev.data_ptr() if perm_dev is not None else None
+        check(self.lib.cae_set_cursor(self.handle, 0, slot_first))
+        for b in range(nb):
+            check(self.lib.cae_train_step(self.handle, which, ptr, min(batch_size, n - b * batch_size)))
+        self.num_batches_tracked += nb
+        self.adam_steps += nb
+        return nb
+
+    def forward_backward(self, which, perm_dev, start, size, global_batch):
+        """DP half-step: gradients of sum/global_count into self.grads (caller all-reduces)"""
+        first = self._claim_slots(1)
+        check(self.lib.cae_set_cursor(self.handle, int(start), first))
+        check(self.lib.cae_forward_backward(self.handle, which,
+                                            perm_dev.data_ptr() if perm_dev is not None else None, int(size),
+                                            int(global_batch)))
+        self.num_batches_tracked += 1
+        return first
+
+    def adam_step(self):
+        check(self.lib.cae_adam_step(self.handle))
+        self.adam_steps += 1
+
+    def score(self, x):
+        """eval-mode forward of an explicit batch (B,C,H,W) fp32 CUDA tensor -> (B,C,H,W)"""
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise CaeError("score() needs an fp32 CUDA tensor")
+        x = x.contiguous()
+        out = torch.empty((x.shape[0],) + tuple(self.out_shape), dtype=torch.float32, device=self.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        done = 0
+        while done < x.shape[0]:
+            n = min(self.max_batch, x.shape[0] - done)
+            check(self.lib.cae_score(self.handle, x[done:done + n].data_ptr(), n, out[done:done + n].data_ptr()))
+            done += n
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        x.record_stream(self.stream)
+        out.record_stream(self.stream)
+        return out
+
+    def sync(self):
+        check(self.lib.cae_sync(self.handle))
+
+    # ---- test hook -------------------------------------------------------------------------
+    def debug_read(self, what, index=0, count=None, dtype=np.float32):
+        cap = int(count) if count is not None else (1 << 28)
+        buf = np.empty(cap, dtype=dtype)
+        n = self.lib.cae_debug_read(self.handle, what.encode(), int(index), buf.ctypes.data_as(C.c_void_p), cap)
+        check(n)
+        return buf[:n]
+
+
+# ---- stateless loader kernels ------------------------------------------------------------------
+
+def scan_f32(x):
+    """(nan_count, nanmin, nanmax) of an fp32 CUDA tensor as python numbers (ds_dataset.py:43-58)"""
+    lib = _lib.load()
+    x = x.contiguous()
+    out = (C.c_double * 3)()
+    torch.cuda.synchronize(x.device)
+    check(lib.cae_scan_f32(x.data_ptr(), x.numel(), None, out))
+    return int(out[0]), float(out[1]), float(out[2])
+
+
+def normalise_pack(src, dst, c_off, vmin, vmax, enable=True):
+    """dst[:, c_off:c_off+Cv] = normalise(src) on the device (ds_dataset.py:99-113,137-147).
+    The range is formed in fp64 from python floats and rounded to fp32, as numpy does."""
+    lib = _lib.load()
+    (n, c_src) = (int(src.shape[0]), int(src.shape[1]))
+    hw = int(np.prod(src.shape[2:]))
+    rng = float(vmax) - float(vmin)
+    check(lib.cae_normalise_pack(src.data_ptr(), n, c_src, hw, dst.data_ptr(), int(dst.shape[1]), int(c_off),
+                                 C.c_float(float(np.float32(vmin))), C.c_float(float(np.float32(rng))),
+                                 1 if enable else 0, torch.cuda.current_stream(src.device).cuda_stream))
+
+
+def denormalise_f64(y, vmin, vmax):
+    """float64 CUDA tensor min + y*(max-min) (ds_dataset.py:131-135 on base_model.py:123's fp64 array)"""
+    lib = _lib.load()
+    y = y.contiguous()
+    out = torch.empty(y.shape, dtype=torch.float64, device=y.device)
+    check(lib.cae_denormalise_f64(y.data_ptr(), y.numel(), float(vmin), float(vmax) - float(vmin), out.data_ptr(),
+                                  torch.cuda.current_stream(y.device).cuda_stream))
+    return out

@@ -1,0 +1,163 @@
+/* cae_hip.h — C ABI of libcae_hip.so, the MI355X (gfx950) implementation of the
+ * cae_tools ConvAEModel hot path.
+ *
+ * The reference (surftemp/cae_tools) has no FFI layer: its hot path is Python on PyTorch.
+ * This ABI is what a maintainer binds (ctypes stub: INTEGRATION.md) to replace these
+ * reference sites, cited per entry point as file:line under src/cae_tools/:
+ *
+ *   models/model_sizer.py:16-67     LayerSpec                     -> cae_layer_spec
+ *   models/encoder.py:36-64         Encoder.__init__/forward      -> cae_engine_create / cae_score / cae_train_step
+ *   models/decoder.py:24-78         Decoder.__init__/forward      -> (same engine)
+ *   models/conv_ae_model.py:185-203 ConvAEModel.__train_epoch     -> cae_set_cursor + cae_train_step per batch + cae_read_losses
+ *   models/conv_ae_model.py:205-221 ConvAEModel.__test_epoch      -> cae_eval_step per batch + cae_read_losses
+ *   models/conv_ae_model.py:223-239 ConvAEModel.score             -> cae_score
+ *   models/conv_ae_model.py:303,310 MSELoss, Adam(lr, weight_decay)-> cae_set_hyper, fused in cae_train_step
+ *   models/ds_dataset.py:43-67      NaN count / nanmin / nanmax   -> cae_scan_f32
+ *   models/ds_dataset.py:99-113,137-147 normalise + channel concat -> cae_normalise_pack
+ *   models/ds_dataset.py:131-135    denormalise_output            -> cae_denormalise_f64
+ *
+ * Conventions: plain pointers and sizes only.  Every pointer named *_dev is DEVICE memory
+ * owned by the caller (the Python host allocates it as torch tensors and passes data_ptr());
+ * the engine owns no device memory except its captured hipGraphs.  All work is enqueued on
+ * the stream given to cae_set_stream (default: the NULL stream) and is asynchronous unless
+ * stated.  Functions return 0 on success or a negative cae_status; cae_last_error() gives the
+ * message for the calling thread.  One engine is used from one host thread at a time.
+ * All arithmetic is fp32 (fp64 only inside reductions and in cae_denormalise_f64).
+ */
+#ifndef CAE_HIP_H
+#define CAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cae_engine cae_engine;
+
+enum cae_status {
+    CAE_OK = 0,
+    CAE_ERR_ARG = -1,      /* bad argument / unsupported geometry */
+    CAE_ERR_STATE = -2,    /* call out of order (not bound, no dataset, ...) */
+    CAE_ERR_HIP = -3       /* a HIP runtime call failed; message carries hipGetErrorString */
+};
+
+/* One convolutional layer: the fields of model_sizer.LayerSpec (model_sizer.py:16-23) with
+ * kernel_size split into (k_h, k_w).  Encoder layers are Conv2d(k, stride, padding 0)
+ * (encoder.py:43-44); decoder layers are ConvTranspose2d(k, stride, padding 0, output_padding)
+ * (decoder.py:44-45). */
+typedef struct {
+    int32_t in_c, in_h, in_w;
+    int32_t out_c, out_h, out_w;
+    int32_t k_h, k_w;
+    int32_t stride;
+    int32_t output_padding;
+} cae_layer_spec;
+
+/* One named tensor of the model: a slice of the flat parameter arena (arena 0) or of the
+ * BatchNorm running-statistics arena (arena 1).  `name` is the reference's state_dict key with
+ * an "enc/" or "dec/" prefix, e.g. "dec/decoder_conv.3.weight"; shapes are PyTorch's
+ * (Conv2d (Cout,Cin,kh,kw); ConvTranspose2d (Cin,Cout,kh,kw); Linear (out,in)). */
+typedef struct {
+    char name[96];
+    int32_t arena;
+    int32_t ndim;
+    int64_t shape[4];
+    int64_t offset;  /* in floats from the arena base */
+    int64_t numel;
+} cae_tensor_info_t;
+
+const char* cae_last_error(void);
+int cae_abi_version(void);
+
+/* ---- engine lifetime and geometry ------------------------------------------------------ */
+
+/* Build the launch plan for an encoder/decoder pair (encoder.py:36-58, decoder.py:24-50).
+ * max_batch bounds every later `batch` argument and sizes the workspace. */
+int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec* dec, int n_dec,
+                      int fc_size, int latent_size, int max_batch, cae_engine** out);
+void cae_engine_destroy(cae_engine* e);
+
+int64_t cae_param_count(const cae_engine* e);   /* floats in the parameter arena */
+int64_t cae_buffer_count(const cae_engine* e);  /* floats in the running-stat arena */
+int cae_tensor_count(const cae_engine* e);
+int cae_tensor_info(const cae_engine* e, int index, cae_tensor_info_t* out);
+int64_t cae_workspace_bytes(const cae_engine* e);
+
+/* Device memory the engine works on.  params/grads/exp_avg/exp_avg_sq: cae_param_count floats
+ * each; buffers: cae_buffer_count floats; workspace: cae_workspace_bytes bytes, 256-B aligned,
+ * zero-filled by the caller before the first use. */
+int cae_bind(cae_engine* e, float* params_dev, float* grads_dev, float* exp_avg_dev,
+             float* exp_avg_sq_dev, float* buffers_dev, void* workspace_dev, int64_t workspace_bytes);
+int cae_set_stream(cae_engine* e, void* hip_stream);
+/* 1: replay each step from a captured hipGraph (default); 0: plain launches */
+int cae_set_graph_mode(cae_engine* e, int enabled);
+
+/* torch.optim.Adam(lr, betas, eps, weight_decay) with L2 decay added to the gradient
+ * (conv_ae_model.py:310). */
+int cae_set_hyper(cae_engine* e, double lr, double beta1, double beta2, double eps, double weight_decay);
+
+/* ---- data ------------------------------------------------------------------------------ */
+
+/* A device-resident, already normalised dataset: x (n, in_c, in_h, in_w), t (n, out_c, out_h,
+ * out_w), both fp32 NCHW.  which: 0 = training set, 1 = test set.  t may be NULL for scoring. */
+int cae_set_dataset(cae_engine* e, int which, const float* x_dev, const float* t_dev, int64_t n);
+
+/* Device-side cursor shared by the step functions: the next batch takes samples
+ * perm[batch_start .. batch_start+batch) and adds its loss to loss slot `loss_slot`; every
+ * step advances batch_start by its batch and loss_slot by one.  (The reference keeps a frozen
+ * list of batches, conv_ae_model.py:315-325; here the frozen object is the permutation.) */
+int cae_set_cursor(cae_engine* e, int64_t batch_start, int loss_slot);
+int cae_set_adam_step(cae_engine* e, int completed_steps);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* One iteration of __train_epoch (conv_ae_model.py:189-200): train-mode forward (batch-stat
+ * BatchNorm, running stats updated), MSE loss, backward, Adam step.  perm_dev: int32 sample
+ * indices into dataset `which` (NULL = identity). */
+int cae_train_step(cae_engine* e, int which, const int32_t* perm_dev, int batch);
+
+/* Data-parallel split of the same step: forward+backward leaves the fp32 gradient of
+ * sum(loss terms)/global_count in grads_dev (to be all-reduced by the caller), then
+ * cae_adam_step applies Adam from grads_dev.  global_batch = batch summed over ranks. */
+int cae_forward_backward(cae_engine* e, int which, const int32_t* perm_dev, int batch, int global_batch);
+int cae_adam_step(cae_engine* e);
+
+/* One iteration of __test_epoch (conv_ae_model.py:205-221): eval-mode forward + MSE into the
+ * loss slot; nothing else is written. */
+int cae_eval_step(cae_engine* e, int which, const int32_t* perm_dev, int batch);
+
+/* score() for one batch (conv_ae_model.py:223-239): eval-mode forward of x_dev (batch, in_c,
+ * in_h, in_w) into y_dev (batch, out_c, out_h, out_w). */
+int cae_score(cae_engine* e, const float* x_dev, int batch, float* y_dev);
+
+/* Blocking: wait for the stream, copy `count` per-step mean losses starting at slot `first`
+ * to host memory, and zero those slots. */
+int cae_read_losses(cae_engine* e, int first, int count, double* host_out);
+int cae_loss_slots(const cae_engine* e);
+int cae_sync(cae_engine* e);
+
+/* Test hook (blocking): copy an internal tensor of the LAST train-mode step to host.
+ * what: "act" raw conv output of layer `index` (encoder layers first, then decoder layers except
+ * the last), "latent", "fc" (decoder FC output), "grad_acc" (fp64 gradient accumulator,
+ * `index` ignored, count doubles).  Returns the number of elements copied or a negative status. */
+int64_t cae_debug_read(cae_engine* e, const char* what, int index, void* host_out, int64_t capacity_elems);
+
+/* ---- loader kernels (stateless) ---------------------------------------------------------- */
+
+/* ds_dataset.py:43-46,53-58: out3 = {NaN count, nanmin, nanmax} of n floats (blocking). */
+int cae_scan_f32(const float* x_dev, int64_t n, void* hip_stream, double* out3_host);
+
+/* ds_dataset.py:99-113,137-147: dst[i, c_off + c, :] = (src[i, c, :] - vmin) / range in fp32
+ * (0 when range == 0; plain copy when enable == 0).  src (n, c_src, hw), dst (n, c_dst, hw). */
+int cae_normalise_pack(const float* src_dev, int64_t n, int c_src, int64_t hw, float* dst_dev,
+                       int c_dst, int c_off, float vmin, float range, int enable, void* hip_stream);
+
+/* ds_dataset.py:131-135 on base_model.py:123's float64 array: out = vmin + ((double)y * range). */
+int cae_denormalise_f64(const float* y_dev, int64_t n, double vmin, double range, double* out_dev,
+                        void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAE_HIP_H */

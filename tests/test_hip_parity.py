@@ -1,0 +1,181 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the reference-generated
+golden vectors.  Needs a GPU.
+
+Tolerances (fp32 path, stated per SURVEY.md §7):
+  forward sigmoid outputs            1e-5 absolute (values in [0,1])
+  loss                               1e-6 relative
+  one-step gradients                 1e-4 of the tensor's max |g|   (+1e-9 absolute)
+  parameters after 4 Adam steps      2e-4 relative + 2e-6 absolute; conv biases that feed a
+                                     BatchNorm only |delta| <= 2.5*lr*steps (their gradient is
+                                     rounding noise in the reference - DESIGN.md)
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import MODEL_CASES, GoldenCase, bn_bias_keys, projections, subsample
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(case, graph=True, max_batch=None):
+    from cae_tools_amd.engine import HipEngine
+    eng = HipEngine(case.spec, case.meta["fc"], case.meta["latent"],
+                    max_batch=max_batch or max(8, case.meta["batch"]), graph=graph)
+    eng.load_state(case.group("init/enc/"), case.group("init/dec/"))
+    eng.set_hyper(lr=case.meta["lr"], weight_decay=case.meta["weight_decay"])
+    return eng
+
+
+def _oracle(case):
+    from oracle import cae_oracle as orc
+    return orc.OracleModel(case.spec, case.group("init/enc/"), case.group("init/dec/"),
+                           lr=case.meta["lr"], weight_decay=case.meta["weight_decay"])
+
+
+def _dataset(eng, case):
+    x = torch.from_numpy(np.concatenate([case.x, case.x2])).cuda()
+    t = torch.from_numpy(np.concatenate([case.t, case.t2])).cuda()
+    eng.set_dataset(0, x, t)
+    return x, t
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_eval_forward(name):
+    case = GoldenCase(name)
+    eng = _engine(case)
+    y = eng.score(torch.from_numpy(case.x).cuda()).cpu().numpy()
+    ref = _oracle(case).eval_forward(torch.from_numpy(case.x)).numpy()
+    assert np.abs(y - ref).max() <= 1e-5
+    np.testing.assert_allclose(subsample(y), case["eval0/y_sub"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(projections(y, 77), case["eval0/y_proj"], rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_train_forward_backward(name, graph):
+    case = GoldenCase(name)
+    eng = _engine(case, graph=graph)
+    _dataset(eng, case)
+    b = case.meta["batch"]
+    slot = eng.forward_backward(0, None, 0, b, b)
+    loss = eng._read_losses(slot, 1)[0]
+    assert abs(loss - float(case["train0/loss"])) <= 1e-6 * abs(float(case["train0/loss"])) + 1e-9
+
+    # raw conv outputs of every layer against the oracle's trace
+    orc = _oracle(case)
+    trace = {}
+    orc.loss_and_grads(torch.from_numpy(case.x), torch.from_numpy(case.t), trace=trace)
+    n_enc = len(case.spec["input_layers"])
+    n_dec = len(case.spec["output_layers"])
+    for i in range(n_enc + n_dec - 1):
+        ref = trace[f"enc_conv{i}" if i < n_enc else f"dec_conv{i - n_enc}"].numpy()
+        got = eng.debug_read("act", i, ref.size).reshape(ref.shape)
+        tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= tol, f"layer {i}"
+    got = eng.debug_read("latent", 0, trace["latent"].numel()).reshape(trace["latent"].shape)
+    assert np.abs(got - trace["latent"].numpy()).max() <= 2e-5 * max(1.0, float(trace["latent"].abs().max()))
+
+    eng.sync()
+    noisy = bn_bias_keys(case.spec)
+    for k, ref in case.group("train0/grad/").items():
+        g = eng.grad_view(k).cpu().numpy()
+        scale = float(np.abs(ref).max())
+        if k in noisy:
+            assert np.abs(g).max() <= 1e-6 + 1e-4 * scale  # exactly-zero gradient, computed as zero
+            continue
+        assert np.abs(g - ref).max() <= 1e-4 * scale + 1e-9, k
+    # running statistics after one train-mode forward
+    for k, ref in case.group("train0/buf/").items():
+        if k.endswith("num_batches_tracked"):
+            assert eng.num_batches_tracked == int(ref)
+            continue
+        np.testing.assert_allclose(eng.view(k).cpu().numpy(), ref, rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_adam_steps(name):
+    case = GoldenCase(name)
+    eng = _engine(case)
+    _dataset(eng, case)
+    b, b2 = case.meta["batch"], case.x2.shape[0]
+    losses = []
+    for s in range(case.meta["nsteps"]):
+        losses.append(eng.train_step(0, None, 0 if s % 2 == 0 else b, b if s % 2 == 0 else b2))
+    np.testing.assert_allclose(losses, case["steps/loss"], rtol=2e-5, atol=1e-7)
+    (enc, dec) = eng.export_state()
+    noisy = bn_bias_keys(case.spec)
+    for side, sd in (("enc/", enc), ("dec/", dec)):
+        for k, v in sd.items():
+            ref = case["steps/" + side + k]
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == int(ref)
+            elif side + k in noisy:
+                assert np.abs(v.numpy() - ref).max() <= 2.5 * case.meta["lr"] * case.meta["nsteps"], k
+            else:
+                np.testing.assert_allclose(v.numpy(), ref, rtol=2e-4, atol=2e-6, err_msg=side + k)
+    y = eng.score(torch.from_numpy(case.x).cuda()).cpu().numpy()
+    np.testing.assert_allclose(subsample(y), case["steps/eval_y_sub"], rtol=0, atol=1e-4)
+
+
+def test_epoch_with_permutation_and_partial_batch():
+    """run_batches: gathered samples through a permutation, last batch partial (drop_last=False)"""
+    case = GoldenCase("cfg1_b3")
+    eng = _engine(case)
+    x, t = _dataset(eng, case)
+    n = x.shape[0]  # 5 samples
+    perm = np.array([3, 0, 4, 1, 2], dtype=np.int32)
+    pd = eng.upload_perm(perm)
+    got = eng.run_batches(0, pd, n, 2, train=True)
+    orc = _oracle(case)
+    ref = []
+    xc, tc = x.cpu(), t.cpu()
+    for s in range(0, n, 2):
+        idx = perm[s:s + 2]
+        ref.append(orc.train_step(xc[idx], tc[idx]))
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-7)
+    # eval pass (test epoch) with the updated weights / running stats
+    got_eval = eng.run_batches(0, pd, n, 2, train=False)
+    ref_eval = [orc.eval_loss(xc[perm[s:s + 2]], tc[perm[s:s + 2]]) for s in range(0, n, 2)]
+    np.testing.assert_allclose(got_eval, ref_eval, rtol=1e-4, atol=1e-7)
+
+
+def test_loader_kernels_bit_exact():
+    import json, os
+    from helpers import GOLDEN
+    from cae_tools_amd.engine import scan_f32, normalise_pack, denormalise_f64
+    npz = np.load(os.path.join(GOLDEN, "ds_dataset.npz"), allow_pickle=False)
+    meta = json.load(open(os.path.join(GOLDEN, "ds_dataset.json")))
+    (mins, maxs, omin, omax) = meta["normalisation_parameters"]
+    names = meta["input_names"]
+    n = npz["lowres"].shape[0]
+    ctot = sum(npz[k].shape[1] for k in names)
+    dst = torch.zeros((n, ctot) + npz["lowres"].shape[2:], dtype=torch.float32, device="cuda")
+    off = 0
+    for k in names:
+        src = torch.from_numpy(npz[k]).cuda()
+        (nans, lo, hi) = scan_f32(src)
+        assert (nans, lo, hi) == (0, mins[k], maxs[k])
+        normalise_pack(src, dst, off, lo, hi)
+        off += src.shape[1]
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dst.cpu().numpy(), npz["norm_in"])
+    hires = torch.from_numpy(npz["hires"]).cuda()
+    out = torch.zeros_like(hires)
+    normalise_pack(hires, out, 0, omin, omax)
+    np.testing.assert_array_equal(out.cpu().numpy(), npz["norm_out"])
+    raw = torch.zeros_like(dst)
+    off = 0
+    for k in names:
+        src = torch.from_numpy(npz[k]).cuda()
+        normalise_pack(src, raw, off, 0.0, 0.0, enable=False)
+        off += src.shape[1]
+    np.testing.assert_array_equal(raw.cpu().numpy()[2], npz["raw_in2"])
+    # NaN counting
+    bad = npz["lowres"].copy(); bad[0, 0, 0, 0] = np.nan; bad[3, 0, 1, 1] = np.nan
+    (nans, lo, hi) = scan_f32(torch.from_numpy(bad).cuda())
+    assert nans == 2 and lo == float(np.nanmin(bad)) and hi == float(np.nanmax(bad))
+    # denormalise: float32 scores -> float64, bit exact with numpy's fp64 expression
+    y32 = npz["denorm_in"].astype(np.float32)
+    got = denormalise_f64(torch.from_numpy(y32).cuda(), omin, omax).cpu().numpy()
+    np.testing.assert_array_equal(got, omin + (y32.astype(np.float64) * (omax - omin)))
