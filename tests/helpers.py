@@ -83,3 +83,32 @@ def bn_bias_keys(spec):
     for i in range(n - 1):
         keys.add(f"dec/decoder_conv.{3 * i}.bias")
     return keys
+
+
+def oracle_model(case, dtype="float32"):
+    """OracleModel on the case's initial state; dtype float64 gives the 'exact' answer used to
+    express tolerances as a multiple of the reference's own fp32 error"""
+    import torch
+    from oracle import cae_oracle as orc
+    def conv(group):
+        out = OrderedDict()
+        for k, v in group.items():
+            t = torch.as_tensor(np.array(v))
+            out[k] = t.double() if (dtype == "float64" and t.is_floating_point()) else t
+        return out
+    return orc.OracleModel(case.spec, conv(case.group("init/enc/")), conv(case.group("init/dec/")),
+                           lr=case.meta["lr"], weight_decay=case.meta["weight_decay"])
+
+
+def assert_close_as_reference(got, ref32, exact64, name, factor=3.0, floor_rel=1e-5, floor_abs=1e-9):
+    """|got - exact| <= factor * |reference_fp32 - exact| (max norm) + floor_rel * max|exact| + floor_abs:
+    the HIP result may be no further from the fp64 answer than `factor` times the reference's
+    own fp32 rounding error on the same tensor."""
+    got = np.asarray(got, dtype=np.float64)
+    ref32 = np.asarray(ref32, dtype=np.float64)
+    exact64 = np.asarray(exact64, dtype=np.float64)
+    scale = float(np.abs(exact64).max())
+    err_ref = float(np.abs(ref32 - exact64).max())
+    err_got = float(np.abs(got - exact64).max())
+    bound = factor * err_ref + floor_rel * scale + floor_abs
+    assert err_got <= bound, f"{name}: |hip-exact|={err_got:.3e} > {bound:.3e} (reference's own error {err_ref:.3e}, scale {scale:.3e})"

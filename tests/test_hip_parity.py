@@ -4,8 +4,13 @@ golden vectors.  Needs a GPU.
 Tolerances (fp32 path, stated per SURVEY.md §7):
   forward sigmoid outputs            1e-5 absolute (values in [0,1])
   loss                               1e-6 relative
-  one-step gradients                 1e-4 of the tensor's max |g|   (+1e-9 absolute)
-  parameters after 4 Adam steps      2e-4 relative + 2e-6 absolute; conv biases that feed a
+  one-step gradients                 distance to the fp64 answer <= 3x the reference's own fp32
+                                     distance to it on the same tensor + 1e-5 of the tensor's max
+                                     (small-batch BatchNorm makes some cases ill-conditioned: the
+                                     reference itself is off by 3e-3 relative on cfg1_b3)
+  parameters after 4 Adam steps      same criterion + 1% of Adam's displacement bound (lr per step:
+                                     the update m/(sqrt(v)+eps) turns a relative gradient error on
+                                     a near-zero gradient into that fraction of lr); conv biases that feed a
                                      BatchNorm only |delta| <= 2.5*lr*steps (their gradient is
                                      rounding noise in the reference - DESIGN.md)
 """
@@ -13,7 +18,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import MODEL_CASES, GoldenCase, bn_bias_keys, projections, subsample
+from helpers import (MODEL_CASES, GoldenCase, assert_close_as_reference, bn_bias_keys, oracle_model,
+                     projections, subsample)
 
 pytestmark = pytest.mark.gpu
 
@@ -78,13 +84,16 @@ def test_train_forward_backward(name, graph):
 
     eng.sync()
     noisy = bn_bias_keys(case.spec)
+    m64 = oracle_model(case, "float64")
+    m64.loss_and_grads(torch.from_numpy(case.x).double(), torch.from_numpy(case.t).double())
+    exact = m64.grads()
     for k, ref in case.group("train0/grad/").items():
         g = eng.grad_view(k).cpu().numpy()
-        scale = float(np.abs(ref).max())
         if k in noisy:
-            assert np.abs(g).max() <= 1e-6 + 1e-4 * scale  # exactly-zero gradient, computed as zero
+            # exactly zero in exact arithmetic; the HIP path computes it as zero
+            assert np.abs(g).max() <= 1e-6 + 1e-4 * float(np.abs(ref).max())
             continue
-        assert np.abs(g - ref).max() <= 1e-4 * scale + 1e-9, k
+        assert_close_as_reference(g, ref, exact[k].numpy(), k)
     # running statistics after one train-mode forward
     for k, ref in case.group("train0/buf/").items():
         if k.endswith("num_batches_tracked"):
@@ -105,6 +114,12 @@ def test_adam_steps(name):
     np.testing.assert_allclose(losses, case["steps/loss"], rtol=2e-5, atol=1e-7)
     (enc, dec) = eng.export_state()
     noisy = bn_bias_keys(case.spec)
+    m64 = oracle_model(case, "float64")
+    b64 = [(torch.from_numpy(case.x).double(), torch.from_numpy(case.t).double()),
+           (torch.from_numpy(case.x2).double(), torch.from_numpy(case.t2).double())]
+    for s in range(case.meta["nsteps"]):
+        m64.train_step(*b64[s % 2])
+    exact = m64.state()
     for side, sd in (("enc/", enc), ("dec/", dec)):
         for k, v in sd.items():
             ref = case["steps/" + side + k]
@@ -113,7 +128,8 @@ def test_adam_steps(name):
             elif side + k in noisy:
                 assert np.abs(v.numpy() - ref).max() <= 2.5 * case.meta["lr"] * case.meta["nsteps"], k
             else:
-                np.testing.assert_allclose(v.numpy(), ref, rtol=2e-4, atol=2e-6, err_msg=side + k)
+                assert_close_as_reference(v.numpy(), ref, exact[side + k].numpy(), side + k,
+                                          floor_abs=0.01 * case.meta["lr"] * case.meta["nsteps"])
     y = eng.score(torch.from_numpy(case.x).cuda()).cpu().numpy()
     np.testing.assert_allclose(subsample(y), case["steps/eval_y_sub"], rtol=0, atol=1e-4)
 
