@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — train images/sec of the ConvAE hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "cfg2"): ConvAEModel 'conv', 16x16 -> 256x256, 1 channel,
+fc_size 128 / latent 32 (API defaults, conv_ae_model.py:36), batch 64 per GPU, synthetic data,
+random-init weights (torch.manual_seed(0)).  One step = one iteration of __train_epoch
+(conv_ae_model.py:189-200): train-mode forward, MSE, backward, Adam.  Inputs are resident in
+HBM before the timed region.  N > 1: one process per GPU, every rank its own 64-sample batches
+(weak scaling, global batch 64*N), one RCCL all-reduce of the flat fp32 gradient per step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cae_tools_amd.engine import HipEngine  # noqa: E402
+from cae_tools_amd.models.model_sizer import create_model_spec  # noqa: E402
+from cae_tools_amd.models.encoder import Encoder  # noqa: E402
+from cae_tools_amd.models.decoder import Decoder  # noqa: E402
+
+IN_SIZE, OUT_SIZE = (16, 16), (256, 256)
+FC, LATENT, BATCH = 128, 32, 64
+N_TRAIN = 4096
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+# algorithmic bytes per image of a training step at this geometry, B = 64
+ALGO_BYTES_PER_IMAGE = 2862766
+
+
+def build_model(seed=0):
+    spec = create_model_spec(input_size=IN_SIZE, input_channels=1, output_size=OUT_SIZE, output_channels=1)
+    torch.manual_seed(seed)
+    enc = Encoder(spec.get_input_layers(), encoded_space_dim=LATENT, fc_size=FC)
+    dec = Decoder(spec.get_output_layers(), encoded_space_dim=LATENT, fc_size=FC)
+    return spec, enc, dec
+
+
+def synthetic(n, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.rand((n, 1) + IN_SIZE, generator=g, dtype=torch.float32)
+    t = torch.rand((n, 1) + OUT_SIZE, generator=g, dtype=torch.float32)
+    return x.to(device), t.to(device)
+
+
+def cpu_baseline(spec, enc, dec, steps=12, warm=2):
+    """the CPU oracle (torch-CPU restatement pinned to the reference) timed on this box's host cores"""
+    from oracle import cae_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = orc.OracleModel(spec.save(), enc.state_dict(), dec.state_dict(), lr=1e-3, weight_decay=1e-5)
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand((BATCH, 1) + IN_SIZE, generator=g)
+    t = torch.rand((BATCH, 1) + OUT_SIZE, generator=g)
+    for _ in range(warm):
+        m.train_step(x, t)
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        m.train_step(x, t)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": BATCH / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} training steps at batch {BATCH} (median), {warm} warm-up, torch {torch.__version__} CPU"}
+
+
+def roofline_from_profile(recs, steps):
+    """dominant kernel = the (name, layer) with the largest total time over the profiled steps"""
+    agg = {}
+    for (name, layer, us, nbytes) in recs:
+        a = agg.setdefault((name, layer), [0.0, 0, nbytes])
+        a[0] += us
+        a[1] += 1
+    total = sum(a[0] for a in agg.values())
+    (key, (us_sum, count, nbytes)) = max(agg.items(), key=lambda kv: kv[1][0])
+    avg_us = us_sum / count
+    achieved = nbytes / (avg_us * 1e-6) / 1e9
+    table = sorted(((k[0], k[1], v[0] / v[1], v[2], v[0] / total) for k, v in agg.items()), key=lambda r: -r[4])
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": f"{key[0]}[layer {key[1]}]", "avg_us": avg_us, "algorithmic_bytes_per_launch": nbytes,
+            "share_of_step": us_sum / total}, table, total / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--table", action="store_true", help="also print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    spec, enc, dec = build_model(0)
+    eng = HipEngine(spec, FC, LATENT, max_batch=BATCH, device=device)
+    eng.load_state(enc.state_dict(), dec.state_dict())
+    eng.set_hyper(lr=1e-3, weight_decay=1e-5)
+    x, t = synthetic(N_TRAIN, device, 1234 + rank)
+    eng.set_dataset(0, x, t)
+    perm = eng.upload_perm(np.random.default_rng(99 + rank).permutation(N_TRAIN))
+    steps_per_epoch = N_TRAIN // BATCH
+
+    if world == 1:
+        def run(nsteps):
+            done = 0
+            while done < nsteps:
+                n = min(steps_per_epoch, nsteps - done)
+                eng.enqueue_train_steps(0, perm, n * BATCH, BATCH, 0)
+                done += n
+    else:
+        from cae_tools_amd.dp import DataParallel
+        dp = DataParallel(eng, dist)
+
+        def run(nsteps):
+            for s in range(nsteps):
+                dp.train_step(0, perm, (s % steps_per_epoch) * BATCH, BATCH)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    run(args.warmup)
+    eng.sync()
+    torch.cuda.synchronize(device)
+    barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run(args.steps)
+    eng.sync()
+    torch.cuda.synchronize(device)
+    barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    eng._read_losses(0, min(steps_per_epoch, eng.loss_slots))  # drain loss slots (outside the timed region)
+
+    result = None
+    if rank == 0:
+        value = BATCH * world * args.steps / elapsed
+        result = {
+            "metric": "train images/sec (16x16->256x256, batch 64)", "value": value, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: ConvAEModel 'conv' 16x16->256x256 1-ch, fc128/latent32, batch 64 per GPU, "
+                                   "train step = fwd+MSE+bwd+Adam, BatchNorm batch stats per GPU",
+                       "global_batch": BATCH * world, "n_train": N_TRAIN, "params": 112271,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "step_roofline": {"algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE,
+                              "achieved_GBs": value / world * ALGO_BYTES_PER_IMAGE / 1e9,
+                              "frac_of_8TBs": value / world * ALGO_BYTES_PER_IMAGE / 1e9 / HBM_PEAK_GBS},
+        }
+    # per-kernel timing with HIP events on the engine's stream (rank 0, plain launches)
+    if rank == 0:
+        prof_steps = 20
+        eng.profile_begin()
+        eng.enqueue_train_steps(0, perm, prof_steps * BATCH, BATCH, 0)
+        recs = eng.profile_end()
+        eng._read_losses(0, prof_steps)
+        roof, table, step_us = roofline_from_profile(recs, prof_steps)
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                roof["traffic"] = json.load(f).get(roof["kernel"])
+        result["roofline"] = roof
+        result["eager_step_us_sum_of_kernels"] = step_us
+        if args.table:
+            for (name, layer, avg, nbytes, share) in table:
+                print(f"{name:28s} L{layer:<2d} {avg:9.2f} us  {nbytes / 1e6:9.2f} MB  {nbytes / avg / 1e3:8.1f} GB/s"
+                      f"  {100 * share:5.1f}%", file=sys.stderr)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(spec, enc, dec)
+    barrier()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,11 @@ class TensorInfoC(C.Structure):
                 ("offset", C.c_int64), ("numel", C.c_int64)]
 
 
+class ProfileRecC(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("layer", C.c_int32), ("reserved", C.c_int32), ("micros", C.c_double),
+                ("bytes", C.c_double)]
+
+
 # name -> (restype, argtypes); every symbol include/cae_hip.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -50,6 +55,8 @@ SIGNATURES = {
     "cae_loss_slots": (C.c_int, [_P]),
     "cae_sync": (C.c_int, [_P]),
     "cae_debug_read": (C.c_int64, [_P, C.c_char_p, C.c_int, _P, C.c_int64]),
+    "cae_profile_begin": (C.c_int, [_P]),
+    "cae_profile_end": (C.c_int, [_P, C.POINTER(ProfileRecC), C.c_int]),
     "cae_scan_f32": (C.c_int, [_P, C.c_int64, _P, C.POINTER(C.c_double)]),
     "cae_normalise_pack": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_float,
                                      C.c_float, C.c_int, _P]),

@@ -91,6 +91,10 @@ struct cae_engine {
     const float* ds_t[2] = {nullptr, nullptr};
     int64_t ds_n[2] = {0, 0};
     bool graph_mode = true;
+    // profiling (cae_profile_begin/end): every launch bracketed by an event pair, plain launches
+    bool profiling = false;
+    struct ProfRec { const char* name; int layer; double bytes; hipEvent_t e0, e1; };
+    std::vector<ProfRec> prof;
     // key: (op, which, batch, global_batch, perm)
     std::map<std::tuple<int, int, int, int, const void*>, hipGraphExec_t> graphs;
 
@@ -198,13 +202,33 @@ int wgrad_ppb(int64_t positions, int64_t nweights) {
 
 enum Op { OP_TRAIN = 1, OP_FWDBWD = 2, OP_EVAL = 3, OP_ADAM = 4 };
 
+// Brackets one launch with HIP events on the engine's stream while profiling is on.
+// `bytes` = algorithmic bytes of the launch: every operand tensor read once, every result written once.
+struct ProfScope {
+    cae_engine* e;
+    int idx = -1;
+    ProfScope(cae_engine* e_, const char* name, int layer, double bytes) : e(e_) {
+        if (!e->profiling) return;
+        cae_engine::ProfRec r{name, layer, bytes, nullptr, nullptr};
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        (void)hipEventRecord(r.e0, e->stream);
+        e->prof.push_back(r);
+        idx = (int)e->prof.size() - 1;
+    }
+    ~ProfScope() {
+        if (idx >= 0) (void)hipEventRecord(e->prof[idx].e1, e->stream);
+    }
+};
+inline double f4(double n) { return 4.0 * n; }
+
 // ---- the step, as a sequence of launches on e->stream -------------------------------------------
 
 struct StepArgs {
     int which;
     const int32_t* perm;
     int batch;
-    int global_batch;
+    int global_batch;      // loss normalisation: batch summed over data-parallel ranks
+    int bn_batch;          // samples behind the BatchNorm sums (local batch; global under SyncBN)
     bool train;            // train-mode forward (+ backward)
     bool use_cursor;       // samples come from the dataset through the cursor
     const float* x_direct; // score(): explicit input batch
@@ -231,7 +255,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
         } else {
             const ConvLayer& P = e->enc[l - 1];
             big = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
-            bnb = bn_of(e, P, act_mode, (double)a.global_batch * P.hout * P.wout, 1);
+            bnb = bn_of(e, P, act_mode, (double)a.bn_batch * P.hout * P.wout, 1);
         }
         Epi ep = epi_plain(e->fptr(L.act_off));
         if (a.train) {
@@ -239,6 +263,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             ep.stats = e->bn_stats(L.bn_index);
         }
         dim3 grid(grid1((int64_t)B * L.hout * L.wout), L.cout);
+        ProfScope _p(e, a.train ? "enc_conv_fwd" : "enc_conv_eval", (int)l, f4((double)B * (L.in_elems() + L.out_elems())));
         hipLaunchKernelGGL(k_down, grid, dim3(256), lds_bytes(L.cin, L.cout), s, g, big, bnb, e->params + L.w_off,
                            e->params + L.b_off, ep, bn_none(), st);
     }
@@ -246,10 +271,11 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
     {
         const ConvLayer& P = e->enc.back();
         const int hw = P.hout * P.wout;
-        BnDesc bni = bn_of(e, P, act_mode, (double)a.global_batch * hw, 1);
+        BnDesc bni = bn_of(e, P, act_mode, (double)a.bn_batch * hw, 1);
         const float* in = e->fptr(P.act_off);
         for (int i = 0; i < 4; i++) {
             const FcLayer& F = e->fc[i];
+            ProfScope _p(e, "linear_fwd", i, f4((double)B * (F.nin + F.nout) + (double)F.nin * F.nout));
             hipLaunchKernelGGL(k_lin_fwd, dim3(grid1((int64_t)B * F.nout)), dim3(256), lds_bytes(i == 0 ? P.cout : 0, 0),
                                s, B, F.nin, F.nout, in, i == 0 ? bni : bn_none(), hw, e->params + F.w_off,
                                e->params + F.b_off, F.relu ? 1 : 0, e->fptr(F.act_off));
@@ -268,7 +294,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
         } else {
             const ConvLayer& P = e->dec[l - 1];
             small = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
-            bns = bn_of(e, P, act_mode, (double)a.global_batch * P.hout * P.wout, 1);
+            bns = bn_of(e, P, act_mode, (double)a.bn_batch * P.hout * P.wout, 1);
         }
         Epi ep;
         if (!last) {
@@ -279,7 +305,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             }
         } else {
             memset(&ep, 0, sizeof ep);
-            ep.inv_count = (float)(1.0 / ((double)a.global_batch * L.cout * L.hout * L.wout));
+            ep.inv_count = (float)(1.0 / ((double)a.bn_batch * L.cout * L.hout * L.wout));
             ep.losses = e->losses();
             ep.perm = a.perm;
             ep.use_cursor = a.use_cursor ? 1 : 0;
@@ -295,6 +321,8 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             }
         }
         dim3 grid(grid1((int64_t)B * L.hout * L.wout), L.cout);
+        ProfScope _p(e, last ? (a.train ? "dec_convt_last_fwd_loss" : "dec_convt_last_eval") : (a.train ? "dec_convt_fwd" : "dec_convt_eval"), (int)l,
+                     f4((double)B * (L.in_elems() + L.out_elems() * (last && (a.train || a.want_loss) ? 2.0 : 1.0))));
         hipLaunchKernelGGL(k_up, grid, dim3(256), lds_bytes(L.cin, L.cout), s, g, small, bns, e->params + L.w_off,
                            e->params + L.b_off, ep, bn_none(), st);
     }
@@ -320,7 +348,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
         } else {
             gy = src_plain(e->fptr(L.grad_off), L.cout, L.hout, L.wout);
             gy.q = e->fptr(L.act_off);
-            bng = bn_of(e, L, BN_BWD, (double)a.global_batch * L.hout * L.wout, 0);
+            bng = bn_of(e, L, BN_BWD, (double)a.bn_batch * L.hout * L.wout, 0);
         }
         // this layer's input activation
         Src ain;
@@ -347,6 +375,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 bg.scale = 1.0;
             }
             dim3 grid((unsigned)nw, (unsigned)((pos + ppb - 1) / ppb));
+            ProfScope _p(e, "dec_convt_wgrad", l, f4((double)B * (L.in_elems() + L.out_elems() * (last ? 1.0 : 2.0))));
             hipLaunchKernelGGL(k_wgrad, grid, dim3(256), lds_bytes(L.cin, L.cout), s, g, ain, bna, gy, bng,
                                acc + L.w_off, ppb, bg, st);
         }
@@ -365,6 +394,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 bne = bn_of(e, P, BN_SAVED, 0, 0);
             }
             dim3 grid(grid1((int64_t)B * L.hin * L.win), L.cin);
+            ProfScope _p(e, "dec_convt_dgrad", l, f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));
             hipLaunchKernelGGL(k_down, grid, dim3(256), lds_bytes(L.cout, L.cin), s, g, gy, bng, e->params + L.w_off,
                                (const float*)nullptr, ep, bne, st);
         }
@@ -378,16 +408,21 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             const float* gout = e->fptr(F.grad_off);
             const float* in = i == 0 ? e->fptr(P.act_off) : e->fptr(e->fc[i - 1].act_off);
             BnDesc bni = i == 0 ? bn_of(e, P, BN_SAVED, 0, 0) : bn_none();
-            hipLaunchKernelGGL(k_lin_wgrad, dim3(grid1((int64_t)F.nin * F.nout)), dim3(256),
-                               lds_bytes(i == 0 ? P.cout : 0, 0), s, B, F.nin, F.nout, gout, in, bni, hw,
-                               acc + F.w_off, acc + F.b_off);
+            {
+                ProfScope _p(e, "linear_wgrad", i, f4((double)B * (F.nin + F.nout)) + 8.0 * F.nin * F.nout);
+                hipLaunchKernelGGL(k_lin_wgrad, dim3(grid1((int64_t)F.nin * F.nout)), dim3(256),
+                                   lds_bytes(i == 0 ? P.cout : 0, 0), s, B, F.nin, F.nout, gout, in, bni, hw,
+                                   acc + F.w_off, acc + F.b_off);
+            }
             if (i > 0) {
                 const FcLayer& G = e->fc[i - 1];
+                ProfScope _p(e, "linear_dgrad", i, f4((double)B * (2.0 * F.nin + F.nout) + (double)F.nin * F.nout));
                 hipLaunchKernelGGL(k_lin_dgrad, dim3(grid1((int64_t)B * F.nin)), dim3(256), lds_bytes(0, 0), s, B,
                                    F.nin, F.nout, gout, e->params + F.w_off, G.relu ? 1 : 0, e->fptr(G.act_off),
                                    bn_none(), 1, (double*)nullptr, e->fptr(G.grad_off));
             } else {
                 dim3 grid(grid1((int64_t)B * hw), P.cout);
+                ProfScope _p(e, "linear_dgrad", i, f4((double)B * (2.0 * F.nin + F.nout) + (double)F.nin * F.nout));
                 hipLaunchKernelGGL(k_lin_dgrad, grid, dim3(256), lds_bytes(P.cout, 0), s, B, F.nin, F.nout, gout,
                                    e->params + F.w_off, 2, e->fptr(P.act_off), bni, hw, e->bn_stats(P.bn_index),
                                    e->fptr(P.grad_off));
@@ -400,7 +435,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
         ConvGeom g{B, L.cout, L.hout, L.wout, L.cin, L.hin, L.win, L.kh, L.kw, L.stride};
         Src gy = src_plain(e->fptr(L.grad_off), L.cout, L.hout, L.wout);
         gy.q = e->fptr(L.act_off);
-        BnDesc bng = bn_of(e, L, BN_BWD, (double)a.global_batch * L.hout * L.wout, 0);
+        BnDesc bng = bn_of(e, L, BN_BWD, (double)a.bn_batch * L.hout * L.wout, 0);
         Src ain;
         BnDesc bna = bn_none();
         if (l == 0) {
@@ -424,6 +459,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             bg.C = L.cout;
             bg.scale = 1.0;
             dim3 grid((unsigned)nw, (unsigned)((pos + ppb - 1) / ppb));
+            ProfScope _p(e, "enc_conv_wgrad", l, f4((double)B * (L.in_elems() + 2.0 * L.out_elems())));
             hipLaunchKernelGGL(k_wgrad, grid, dim3(256), lds_bytes(L.cout, L.cin), s, g, gy, bng, ain, bna,
                                acc + L.w_off, ppb, bg, st);
         }
@@ -435,6 +471,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             ep.yprev = e->fptr(P.act_off);
             BnDesc bne = bn_of(e, P, BN_SAVED, 0, 0);
             dim3 grid(grid1((int64_t)B * L.hin * L.win), L.cin);
+            ProfScope _p(e, "enc_conv_dgrad", l, f4((double)B * (2.0 * L.out_elems() + 2.0 * L.in_elems())));
             hipLaunchKernelGGL(k_up, grid, dim3(256), lds_bytes(L.cout, L.cin), s, g, gy, bng, e->params + L.w_off,
                                (const float*)nullptr, ep, bne, st);
         }
@@ -445,12 +482,16 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
 int launch_op(cae_engine* e, int op, const StepArgs& a) {
     hipStream_t s = e->stream;
     if (op == OP_TRAIN || op == OP_FWDBWD) {
-        HIP_TRY(hipMemsetAsync(e->ws + e->off_zero_begin, 0, (size_t)(e->off_zero_end - e->off_zero_begin), s));
+        {
+            ProfScope _p(e, "zero_accumulators", 0, (double)(e->off_zero_end - e->off_zero_begin));
+            HIP_TRY(hipMemsetAsync(e->ws + e->off_zero_begin, 0, (size_t)(e->off_zero_end - e->off_zero_begin), s));
+        }
         int rc = launch_forward(e, a);
         if (rc) return rc;
         rc = launch_backward(e, a);
         if (rc) return rc;
         if (op == OP_TRAIN) {
+            ProfScope _p(e, "adam", 0, 32.0 * e->n_param);
             hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
                                (const double*)e->gradacc(), (const float*)nullptr, e->m, e->v, e->hp,
                                (const StepState*)e->state());
@@ -477,7 +518,7 @@ int launch_op(cae_engine* e, int op, const StepArgs& a) {
 // run an op either directly or through a cached hipGraph
 int run_op(cae_engine* e, int op, const StepArgs& a, bool cacheable) {
     // the legacy NULL stream cannot be captured: plain launches there
-    if (!e->graph_mode || !cacheable || e->stream == nullptr) return launch_op(e, op, a);
+    if (!e->graph_mode || !cacheable || e->stream == nullptr || e->profiling) return launch_op(e, op, a);
     auto key = std::make_tuple(op, a.which, a.batch, a.global_batch, (const void*)a.perm);
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
@@ -754,7 +795,7 @@ int cae_set_adam_step(cae_engine* e, int completed_steps) {
 int cae_train_step(cae_engine* e, int which, const int32_t* perm, int batch) {
     int rc = check_ready(e, which, batch, true);
     if (rc) return rc;
-    StepArgs a{which, perm, batch, batch, true, true, nullptr, nullptr, true};
+    StepArgs a{which, perm, batch, batch, batch, true, true, nullptr, nullptr, true};
     return run_op(e, OP_TRAIN, a, true);
 }
 
@@ -762,20 +803,20 @@ int cae_forward_backward(cae_engine* e, int which, const int32_t* perm, int batc
     int rc = check_ready(e, which, batch, true);
     if (rc) return rc;
     if (global_batch < batch) return fail(CAE_ERR_ARG, "global_batch < batch");
-    StepArgs a{which, perm, batch, global_batch, true, true, nullptr, nullptr, true};
+    StepArgs a{which, perm, batch, global_batch, batch, true, true, nullptr, nullptr, true};
     return run_op(e, OP_FWDBWD, a, true);
 }
 
 int cae_adam_step(cae_engine* e) {
     if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
-    StepArgs a{0, nullptr, 0, 0, false, false, nullptr, nullptr, false};
+    StepArgs a{0, nullptr, 0, 0, 0, false, false, nullptr, nullptr, false};
     return run_op(e, OP_ADAM, a, true);
 }
 
 int cae_eval_step(cae_engine* e, int which, const int32_t* perm, int batch) {
     int rc = check_ready(e, which, batch, true);
     if (rc) return rc;
-    StepArgs a{which, perm, batch, batch, false, true, nullptr, nullptr, true};
+    StepArgs a{which, perm, batch, batch, batch, false, true, nullptr, nullptr, true};
     return run_op(e, OP_EVAL, a, true);
 }
 
@@ -783,7 +824,7 @@ int cae_score(cae_engine* e, const float* x, int batch, float* y) {
     if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
     if (!x || !y) return fail(CAE_ERR_ARG, "cae_score: null pointer");
     if (batch < 1 || batch > e->max_batch) return fail(CAE_ERR_ARG, "batch %d outside [1, %d]", batch, e->max_batch);
-    StepArgs a{0, nullptr, batch, batch, false, false, x, y, false};
+    StepArgs a{0, nullptr, batch, batch, batch, false, false, x, y, false};
     return run_op(e, OP_EVAL, a, false);
 }
 
@@ -850,6 +891,40 @@ int64_t cae_debug_read(cae_engine* e, const char* what, int index, void* host_ou
     if (n > cap) n = cap;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(host_out, src, (size_t)(n * esz), hipMemcpyDeviceToHost));
+    return n;
+}
+
+int cae_profile_begin(cae_engine* e) {
+    if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+    for (auto& r : e->prof) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    e->prof.clear();
+    e->profiling = true;
+    return CAE_OK;
+}
+
+int cae_profile_end(cae_engine* e, cae_profile_rec* out, int capacity) {
+    if (!e) return fail(CAE_ERR_ARG, "null engine");
+    e->profiling = false;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int n = 0;
+    for (auto& r : e->prof) {
+        float ms = 0.f;
+        hipError_t rc = hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (rc == hipSuccess && out && n < capacity) {
+            memset(&out[n], 0, sizeof out[n]);
+            snprintf(out[n].name, sizeof out[n].name, "%s", r.name);
+            out[n].layer = r.layer;
+            out[n].micros = (double)ms * 1000.0;
+            out[n].bytes = r.bytes;
+            n++;
+        }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    e->prof.clear();
     return n;
 }
 

@@ -295,6 +295,17 @@ class HipEngine(EnginePlan):
     def sync(self):
         check(self.lib.cae_sync(self.handle))
 
+    # ---- measurement -----------------------------------------------------------------------
+    def profile_begin(self):
+        check(self.lib.cae_profile_begin(self.handle))
+
+    def profile_end(self, capacity=65536):
+        """[(name, layer, microseconds, algorithmic_bytes)] for every launch since profile_begin"""
+        recs = (_lib.ProfileRecC * capacity)()
+        n = check(self.lib.cae_profile_end(self.handle, recs, capacity))
+        return [(recs[i].name.decode(), int(recs[i].layer), float(recs[i].micros), float(recs[i].bytes))
+                for i in range(n)]
+
     # ---- test hook -------------------------------------------------------------------------
     def debug_read(self, what, index=0, count=None, dtype=np.float32):
         cap = int(count) if count is not None else (1 << 28)

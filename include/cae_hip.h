@@ -143,6 +143,23 @@ int cae_sync(cae_engine* e);
  * `index` ignored, count doubles).  Returns the number of elements copied or a negative status. */
 int64_t cae_debug_read(cae_engine* e, const char* what, int index, void* host_out, int64_t capacity_elems);
 
+/* ---- measurement ------------------------------------------------------------------------- */
+
+/* Per-launch timing for bench.py's roofline figure.  Between begin and end every kernel launch
+ * of the step functions is bracketed by a HIP event pair on the engine's stream (plain launches,
+ * no graph replay).  cae_profile_end blocks, fills up to `capacity` records in launch order and
+ * returns their number.  bytes = algorithmic bytes of the launch (each operand tensor read once,
+ * each result written once). */
+typedef struct {
+    char name[48];
+    int32_t layer;
+    int32_t reserved;
+    double micros;
+    double bytes;
+} cae_profile_rec;
+int cae_profile_begin(cae_engine* e);
+int cae_profile_end(cae_engine* e, cae_profile_rec* out, int capacity);
+
 /* ---- loader kernels (stateless) ---------------------------------------------------------- */
 
 /* ds_dataset.py:43-46,53-58: out3 = {NaN count, nanmin, nanmax} of n floats (blocking). */
