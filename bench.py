@@ -57,22 +57,36 @@ def synthetic(n, device, seed):
 def cpu_baseline(spec, enc, dec, steps=12, warm=2):
     """the CPU oracle (torch-CPU restatement pinned to the reference) timed on this box's host cores"""
     from oracle import cae_oracle as orc
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    m = orc.OracleModel(spec.save(), enc.state_dict(), dec.state_dict(), lr=1e-3, weight_decay=1e-5)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # a one-GPU box is given a 16-core share of the host; more intra-op threads than that only
+    # oversubscribes (256 threads: 22 s per step).  Time 16 and 8 threads, report the faster.
     g = torch.Generator().manual_seed(7)
     x = torch.rand((BATCH, 1) + IN_SIZE, generator=g)
     t = torch.rand((BATCH, 1) + OUT_SIZE, generator=g)
-    for _ in range(warm):
-        m.train_step(x, t)
-    times = []
-    for _ in range(steps):
-        t0 = time.perf_counter()
-        m.train_step(x, t)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return {"value": BATCH / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} training steps at batch {BATCH} (median), {warm} warm-up, torch {torch.__version__} CPU"}
+    best = None
+    for cores in sorted({min(avail, 16), min(avail, 8)}, reverse=True):
+        torch.set_num_threads(cores)
+        m = orc.OracleModel(spec.save(), enc.state_dict(), dec.state_dict(), lr=1e-3, weight_decay=1e-5)
+        for _ in range(warm):
+            m.train_step(x, t)
+        times = []
+        budget = time.perf_counter() + 12.0
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            m.train_step(x, t)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() > budget:
+                break
+        med = float(np.median(times))
+        if best is None or med < best[0]:
+            best = (med, cores, len(times))
+    (med, cores, n) = best
+    return {"value": BATCH / med, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} training steps at batch {BATCH} (median), {warm} warm-up, torch {torch.__version__} CPU, "
+                      f"{cores} intra-op threads (host reports {os.cpu_count()} CPUs)"}
 
 
 def roofline_from_profile(recs, steps):

@@ -71,6 +71,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so, same soname as /opt/rocm's).  It must
+    # be the one already loaded when libcae_hip.so resolves libamdhip64.so.7, otherwise the process
+    # holds two runtimes and torch's streams / device pointers mean nothing to ours.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise CaeError(f"{LIB_PATH} is missing: build it with `python -m cae_tools_amd.build` "
                        "(hipcc --offload-arch=gfx950). cae_tools_amd has no CPU fallback.")

@@ -178,6 +178,17 @@ class HipEngine(EnginePlan):
         torch.cuda.synchronize(self.device)
         check(self.lib.cae_set_adam_step(self.handle, 0))
 
+    def load_optimizer_state(self, moments, step):
+        """moments: {tensor name: (exp_avg, exp_avg_sq)} for parameter tensors; step: completed Adam steps"""
+        self.sync()
+        for name, (m, v) in moments.items():
+            (arena, off, numel, shape) = self.tensors[name]
+            self.exp_avg[off:off + numel].copy_(torch.as_tensor(m, dtype=torch.float32).reshape(-1).to(self.device))
+            self.exp_avg_sq[off:off + numel].copy_(torch.as_tensor(v, dtype=torch.float32).reshape(-1).to(self.device))
+        torch.cuda.synchronize(self.device)
+        self.adam_steps = int(step)
+        check(self.lib.cae_set_adam_step(self.handle, int(step)))
+
     def set_hyper(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5):
         check(self.lib.cae_set_hyper(self.handle, float(lr), float(betas[0]), float(betas[1]), float(eps),
                                      float(weight_decay)))

