@@ -42,6 +42,7 @@ SIGNATURES = {
     "cae_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64]),
     "cae_set_stream": (C.c_int, [_P, _P]),
     "cae_set_graph_mode": (C.c_int, [_P, C.c_int]),
+    "cae_set_kernel_mode": (C.c_int, [_P, C.c_int]),
     "cae_set_hyper": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     "cae_set_dataset": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
     "cae_set_cursor": (C.c_int, [_P, C.c_int64, C.c_int]),

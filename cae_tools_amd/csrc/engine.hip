@@ -13,6 +13,7 @@
 
 #include "cae_hip.h"
 #include "kernels_generic.h"
+#include "kernels_s2.h"
 
 using namespace cae;
 
@@ -91,6 +92,7 @@ struct cae_engine {
     const float* ds_t[2] = {nullptr, nullptr};
     int64_t ds_n[2] = {0, 0};
     bool graph_mode = true;
+    bool use_s2 = true;  // specialised stride-2 kernels (cae_set_kernel_mode)
     // profiling (cae_profile_begin/end): every launch bracketed by an event pair, plain launches
     bool profiling = false;
     struct ProfRec { const char* name; int layer; double bytes; hipEvent_t e0, e1; };
@@ -236,6 +238,65 @@ struct StepArgs {
     bool want_loss;        // eval: accumulate MSE into the loss slot
 };
 
+// ---- specialised stride-2 kernels (kernels_s2.h): dispatch on (Cin, Cout, kh, kw) ----------------
+
+#define S2_SHAPES(X) X(2, 1) X(4, 2) X(8, 4) X(6, 3)
+#define S2_KERNELS(X, CI, CO) X(CI, CO, 3, 3) X(CI, CO, 4, 4) X(CI, CO, 3, 4) X(CI, CO, 4, 3)
+
+bool s2_eligible(const cae_engine* e, const ConvLayer& L) {
+    if (!e->use_s2 || !L.transposed || L.stride != 2) return false;
+    if (L.kh < 3 || L.kh > 4 || L.kw < 3 || L.kw > 4) return false;
+#define CHK(CI, CO) if (L.cin == CI && L.cout == CO) return true;
+    S2_SHAPES(CHK)
+#undef CHK
+    return false;
+}
+
+template <int CIN, int COUT, int KH, int KW>
+void s2_fwd_launch(S2Fwd a, hipStream_t s) {
+    const int qx = (a.OW + 1) / 2, qy = (a.OH + 1) / 2;
+    if (qx > 32) {
+        a.tiles_x = (qx + 63) / 64;
+        a.tiles_y = (qy + 3) / 4;
+        hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 64>), dim3(a.B * a.tiles_x * a.tiles_y), dim3(256), 0, s, a);
+    } else {
+        a.tiles_x = (qx + 31) / 32;
+        a.tiles_y = (qy + 7) / 8;
+        hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 32>), dim3(a.B * a.tiles_x * a.tiles_y), dim3(256), 0, s, a);
+    }
+}
+
+void s2_fwd_dispatch(const ConvLayer& L, const S2Fwd& a, hipStream_t s) {
+#define ONE(CI, CO, KH_, KW_) \
+    if (L.cin == CI && L.cout == CO && L.kh == KH_ && L.kw == KW_) return s2_fwd_launch<CI, CO, KH_, KW_>(a, s);
+#define PAIR(CI, CO) S2_KERNELS(ONE, CI, CO)
+    S2_SHAPES(PAIR)
+#undef PAIR
+#undef ONE
+}
+
+template <int CIN, int COUT, int KH, int KW>
+void s2_bwd_launch(S2Bwd a, hipStream_t s) {
+    constexpr int CT = (CIN % 2 == 0 && CIN != 6) ? 2 : 3;   // input channels per thread
+    constexpr int CG = CIN / CT;                              // ci-groups per workgroup
+    constexpr int PIX = 256 / CG;                             // pixels per tile
+    constexpr int TPX = 32, TPY = PIX / 32;
+    a.tiles_x = (a.W + TPX - 1) / TPX;
+    a.tiles_y = (a.H + TPY - 1) / TPY;
+    a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+    const int grid = a.total_tiles < 768 ? a.total_tiles : 768;
+    hipLaunchKernelGGL((k_s2_bwd<CIN, CT, COUT, KH, KW, TPX, TPY>), dim3(grid), dim3(256), 0, s, a);
+}
+
+void s2_bwd_dispatch(const ConvLayer& L, const S2Bwd& a, hipStream_t s) {
+#define ONE(CI, CO, KH_, KW_) \
+    if (L.cin == CI && L.cout == CO && L.kh == KH_ && L.kw == KW_) return s2_bwd_launch<CI, CO, KH_, KW_>(a, s);
+#define PAIR(CI, CO) S2_KERNELS(ONE, CI, CO)
+    S2_SHAPES(PAIR)
+#undef PAIR
+#undef ONE
+}
+
 int launch_forward(cae_engine* e, const StepArgs& a) {
     hipStream_t s = e->stream;
     const int B = a.batch;
@@ -320,6 +381,34 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
                 ep.target = a.want_loss ? e->ds_t[a.which] : nullptr;
             }
         }
+        if (s2_eligible(e, L)) {
+            S2Fwd f;
+            memset(&f, 0, sizeof f);
+            f.B = B; f.H = L.hin; f.W = L.win; f.OH = L.hout; f.OW = L.wout;
+            f.in = small.p;
+            f.w = e->params + L.w_off;
+            f.bias = e->params + L.b_off;
+            f.bn_in = bns;
+            f.st = st;
+            if (!last) {
+                f.out = ep.out;
+                f.stats = ep.stats;
+                f.epi = a.train ? S2_RAW_STATS : S2_RAW;
+            } else {
+                f.out = a.train ? ep.out : ep.yhat;
+                f.target = ep.target;
+                f.perm = ep.perm;
+                f.use_cursor = ep.use_cursor;
+                f.losses = ep.losses;
+                f.inv_count = ep.inv_count;
+                f.bias_acc = ep.bias_acc;
+                f.epi = a.train ? S2_SIGMSE : S2_SIGOUT;
+            }
+            ProfScope _p(e, last ? (a.train ? "s2_convt_last_fwd_loss" : "s2_convt_last_eval") : (a.train ? "s2_convt_fwd" : "s2_convt_eval"), (int)l,
+                         f4((double)B * (L.in_elems() + L.out_elems() * (last && (a.train || a.want_loss) ? 2.0 : 1.0))));
+            s2_fwd_dispatch(L, f, s);
+            continue;
+        }
         dim3 grid(grid1((int64_t)B * L.hout * L.wout), L.cout);
         ProfScope _p(e, last ? (a.train ? "dec_convt_last_fwd_loss" : "dec_convt_last_eval") : (a.train ? "dec_convt_fwd" : "dec_convt_eval"), (int)l,
                      f4((double)B * (L.in_elems() + L.out_elems() * (last && (a.train || a.want_loss) ? 2.0 : 1.0))));
@@ -359,6 +448,36 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             const ConvLayer& P = e->dec[l - 1];
             ain = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
             bna = bn_of(e, P, BN_SAVED, 0, 0);
+        }
+        if (s2_eligible(e, L)) {
+            S2Bwd f;
+            memset(&f, 0, sizeof f);
+            f.B = B; f.H = L.hin; f.W = L.win; f.OH = L.hout; f.OW = L.wout;
+            f.g = gy.p;
+            f.yout = gy.q;
+            f.bn_out = bng;
+            f.ain = ain.p;
+            f.bn_in = bna;
+            f.w = e->params + L.w_off;
+            f.wacc = acc + L.w_off;
+            if (l == 0) {
+                f.gin = e->fptr(e->fc[3].grad_off);
+            } else {
+                const ConvLayer& P = e->dec[l - 1];
+                f.gin = e->fptr(P.grad_off);
+                f.stats_in = e->bn_stats(P.bn_index);
+            }
+            if (L.has_bn) {
+                f.bg.stats = e->bn_stats(L.bn_index);
+                f.bg.gamma_acc = acc + L.gamma_off;
+                f.bg.beta_acc = acc + L.beta_off;
+                f.bg.C = L.cout;
+                f.bg.scale = 1.0;
+            }
+            ProfScope _p(e, "s2_convt_bwd", l,
+                         f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * 2.0)));
+            s2_bwd_dispatch(L, f, s);
+            continue;
         }
         // weight gradient (+ BN parameter gradients of this layer)
         {
@@ -757,6 +876,13 @@ int cae_set_graph_mode(cae_engine* e, int enabled) {
     if (!e) return fail(CAE_ERR_ARG, "null engine");
     e->graph_mode = enabled != 0;
     if (!e->graph_mode) e->drop_graphs();
+    return CAE_OK;
+}
+
+int cae_set_kernel_mode(cae_engine* e, int specialised) {
+    if (!e) return fail(CAE_ERR_ARG, "null engine");
+    if (e->use_s2 != (specialised != 0)) e->drop_graphs();
+    e->use_s2 = specialised != 0;
     return CAE_OK;
 }
 

@@ -1,0 +1,408 @@
+// kernels_s2.h — specialised gfx950 kernels for the stride-2 ConvTranspose2d layers with few
+// channels (the last decoder layers: 8->4, 4->2, 2->1 at 63..256 px), which carry >80 % of the
+// bytes of a training step.  These layers are pure HBM streaming (<= 18 FLOP per output), so the
+// design goal is: every activation byte crosses the memory system once per pass, coalesced, with
+// BatchNorm/ReLU/sigmoid/MSE/masking folded into the load or the store of the neighbouring conv.
+//
+// Forward (k_s2_fwd): sub-pixel decomposition.  With stride 2 the output pixel (2m+py, 2n+px)
+// only sees inputs (m-j, n-i), j,i in {0,1}, through taps (py+2j, px+2i):
+//     out[co][2m+py][2n+px] = b[co] + sum_ci sum_j,i a[ci][m-j][n-i] * W[ci][co][py+2j][px+2i]
+// One thread owns the "quad" (m,n): it loads the 2x2 input neighbourhood of every input channel
+// once (BN+ReLU applied in registers), produces the 2x2 output block of every output channel,
+// and stores pairs of adjacent pixels.  Lanes run along n, so loads and stores are contiguous.
+//
+// Backward (k_s2_bwd): one pass that computes, from the gradient map gy of the layer's output,
+//   (a) the gradient wrt the layer's input  ga[ci][y][x] = sum_co,k gy[co][2y+ky][2x+kx] W[ci][co][k]
+//       masked by the producer's ReLU and reduced into the producer's BatchNorm sums, and
+//   (b) the weight gradient dW[ci][co][k] = sum_pixels a[ci][y][x] * gy[co][2y+ky][2x+kx],
+// with the BatchNorm-backward transform of gy applied once per element while the tile is staged
+// into LDS (NCHW -> LDS patch tile).  Accumulators stay in registers across all tiles a
+// workgroup walks; one wave-shuffle + LDS reduction and one fp64 atomic per value at the end.
+#pragma once
+#include "kernels_generic.h"
+
+namespace cae {
+
+struct S2Fwd {
+    int B, H, W, OH, OW;     // input map H x W, output map OH x OW (per channel)
+    int tiles_x, tiles_y;    // quad tiles per image
+    const float* in;         // (B, CIN, H, W) raw output of the producer (or plain activations)
+    const float* w;          // (CIN, COUT, KH, KW)
+    const float* bias;       // (COUT)
+    float* out;              // (B, COUT, OH, OW): raw output | dL/d(pre-sigmoid) | sigmoid output
+    BnDesc bn_in;            // BatchNorm(+ReLU) sitting on `in` (BN_NONE: identity)
+    double* stats;           // EPI 0: [COUT][4] sums of the BatchNorm that follows
+    // EPI 1/2 (last layer):
+    const float* target;     // dataset targets (N, COUT, OH, OW) or nullptr
+    const int* perm;
+    int use_cursor;
+    double* losses;
+    float inv_count;
+    double* bias_acc;
+    const StepState* st;
+    int epi;                 // S2_RAW_STATS | S2_RAW | S2_SIGMSE | S2_SIGOUT
+};
+
+enum S2Epi : int { S2_RAW_STATS = 0, S2_SIGMSE = 1, S2_SIGOUT = 2, S2_RAW = 3 };
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// store two horizontally adjacent floats; vectorised when the address allows (wave-uniform test:
+// all lanes of a wave share the row, and columns are even)
+__device__ __forceinline__ void store_pair(float* p, float v0, float v1, bool both) {
+    if (both) {
+        if ((reinterpret_cast<uintptr_t>(p) & 7) == 0) {
+            *reinterpret_cast<float2*>(p) = make_float2(v0, v1);
+        } else {
+            p[0] = v0;
+            p[1] = v1;
+        }
+    } else {
+        p[0] = v0;
+    }
+}
+
+// a.epi (uniform): S2_RAW_STATS = raw output + BatchNorm sums, S2_RAW = raw output only (eval),
+// S2_SIGMSE = sigmoid + MSE + gradient (train, last layer), S2_SIGOUT = sigmoid output (+ optional
+// loss) (eval, last layer)
+template <int CIN, int COUT, int KH, int KW, int TW>
+__global__ void __launch_bounds__(256) k_s2_fwd(S2Fwd a) {
+    const int EPI = a.epi;
+    constexpr int TH = 256 / TW;
+    __shared__ float4 cin4[CIN];
+    __shared__ double red[4 * 2 * COUT];
+    const bool designated = blockIdx.x == 0;
+    {
+        BnDesc d = a.bn_in;
+        bn_consts(d, cin4, designated);
+    }
+    __syncthreads();
+
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int b = blockIdx.x / tiles;
+    const int t = blockIdx.x - b * tiles;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int n = tx * TW + (threadIdx.x % TW);
+    const int m = ty * TH + (threadIdx.x / TW);
+    const bool active = (2 * m < a.OH) && (2 * n < a.OW);
+
+    float acc[COUT][2][2];
+#pragma unroll
+    for (int co = 0; co < COUT; co++) {
+        const float bv = a.bias[co];
+        acc[co][0][0] = acc[co][0][1] = acc[co][1][0] = acc[co][1][1] = bv;
+    }
+    if (active) {
+        const bool r0 = m < a.H, r1 = m >= 1 && m - 1 < a.H;   // rows m (j=0) and m-1 (j=1) exist
+        const bool c0 = n < a.W, c1 = n >= 1 && n - 1 < a.W;   // cols n (i=0) and n-1 (i=1) exist
+        const float* base = a.in + (size_t)b * CIN * a.H * a.W + (size_t)m * a.W + n;
+        // weights are wave-uniform (scalar loads); unrolling every ci would need CIN*COUT*KH*KW live
+        // scalars, so large weight sets walk ci one at a time
+#pragma unroll(CIN * COUT * KH * KW <= 80 ? CIN : 1)
+        for (int ci = 0; ci < CIN; ci++) {
+            const float* p = base + (size_t)ci * a.H * a.W;
+            float v[2][2];
+            v[0][0] = (r0 && c0) ? p[0] : 0.f;
+            v[0][1] = (r0 && c1) ? p[-1] : 0.f;
+            v[1][0] = (r1 && c0) ? p[-a.W] : 0.f;
+            v[1][1] = (r1 && c1) ? p[-a.W - 1] : 0.f;
+            if (a.bn_in.mode != BN_NONE) {
+                const float4 k = cin4[ci];
+                v[0][0] = (r0 && c0) ? fmaxf(0.f, fmaf(v[0][0] - k.x, k.y, k.z)) : 0.f;
+                v[0][1] = (r0 && c1) ? fmaxf(0.f, fmaf(v[0][1] - k.x, k.y, k.z)) : 0.f;
+                v[1][0] = (r1 && c0) ? fmaxf(0.f, fmaf(v[1][0] - k.x, k.y, k.z)) : 0.f;
+                v[1][1] = (r1 && c1) ? fmaxf(0.f, fmaf(v[1][1] - k.x, k.y, k.z)) : 0.f;
+            }
+            const float* wc = a.w + (size_t)ci * COUT * KH * KW;
+#pragma unroll
+            for (int co = 0; co < COUT; co++) {
+#pragma unroll
+                for (int py = 0; py < 2; py++) {
+#pragma unroll
+                    for (int px = 0; px < 2; px++) {
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+#pragma unroll
+                            for (int i = 0; i < 2; i++) {
+                                if (py + 2 * j < KH && px + 2 * i < KW)
+                                    acc[co][py][px] = fmaf(v[j][i], wc[(co * KH + py + 2 * j) * KW + px + 2 * i],
+                                                           acc[co][py][px]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue
+    const int oy = 2 * m, ox = 2 * n;
+    const bool row1 = active && (oy + 1 < a.OH);
+    const bool col1 = active && (ox + 1 < a.OW);
+    double r[2 * COUT];
+#pragma unroll
+    for (int i = 0; i < 2 * COUT; i++) r[i] = 0.0;
+
+    if (EPI == S2_RAW_STATS || EPI == S2_RAW) {
+        if (active) {
+#pragma unroll
+            for (int co = 0; co < COUT; co++) {
+                float* o = a.out + ((size_t)(b * COUT + co) * a.OH + oy) * a.OW + ox;
+                store_pair(o, acc[co][0][0], acc[co][0][1], col1);
+                if (row1) store_pair(o + a.OW, acc[co][1][0], acc[co][1][1], col1);
+                if (EPI == S2_RAW_STATS) {
+                    float s1 = acc[co][0][0], s2 = acc[co][0][0] * acc[co][0][0];
+                    if (col1) { s1 += acc[co][0][1]; s2 = fmaf(acc[co][0][1], acc[co][0][1], s2); }
+                    if (row1) {
+                        s1 += acc[co][1][0]; s2 = fmaf(acc[co][1][0], acc[co][1][0], s2);
+                        if (col1) { s1 += acc[co][1][1]; s2 = fmaf(acc[co][1][1], acc[co][1][1], s2); }
+                    }
+                    r[2 * co] = (double)s1;
+                    r[2 * co + 1] = (double)s2;
+                }
+            }
+        }
+    } else {
+        if (active) {
+            size_t tb = 0;
+            if (a.target) tb = sample_of(a.perm, a.use_cursor, a.st, b);
+#pragma unroll
+            for (int co = 0; co < COUT; co++) {
+                float* o = a.out ? a.out + ((size_t)(b * COUT + co) * a.OH + oy) * a.OW + ox : nullptr;
+                const float* tp = a.target ? a.target + ((tb * COUT + co) * (size_t)a.OH + oy) * a.OW + ox : nullptr;
+                float lsum = 0.f, gsum = 0.f;
+#pragma unroll
+                for (int py = 0; py < 2; py++) {
+                    if (py == 1 && !row1) break;
+                    float res[2];
+#pragma unroll
+                    for (int px = 0; px < 2; px++) {
+                        const bool ok = px == 0 || col1;
+                        const float yh = 1.0f / (1.0f + expf(-acc[co][py][px]));
+                        float outv = yh;
+                        if (tp && ok) {
+                            const float d = yh - tp[py * a.OW + px];
+                            lsum = fmaf(d, d, lsum);
+                            if (EPI == S2_SIGMSE) {
+                                outv = (2.0f * d * a.inv_count) * (yh * (1.0f - yh));
+                                gsum += outv;
+                            }
+                        }
+                        res[px] = outv;
+                    }
+                    if (o) store_pair(o + py * a.OW, res[0], res[1], col1);
+                }
+                r[2 * co] = (double)lsum * (double)a.inv_count;
+                r[2 * co + 1] = (double)gsum;
+            }
+        }
+    }
+
+    if (EPI != S2_RAW) {
+        if (EPI == S2_SIGOUT && !a.target) return;
+        // block reduction of the 2*COUT partials, then one fp64 atomic each
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 2 * COUT; i++) {
+            const double s = wave_sum(r[i]);
+            if (lane == 0) red[wv * 2 * COUT + i] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * COUT) {
+            const int i = threadIdx.x;
+            const double s = red[i] + red[2 * COUT + i] + red[4 * COUT + i] + red[6 * COUT + i];
+            const int co = i >> 1;
+            if (EPI == S2_RAW_STATS) {
+                atomicAdd(&a.stats[4 * co + (i & 1)], s);
+            } else {
+                if ((i & 1) == 0) {
+                    atomicAdd(&a.losses[a.st->loss_slot], s);
+                } else if (EPI == S2_SIGMSE) {
+                    atomicAdd(&a.bias_acc[co], s);
+                }
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// fused backward of a thin stride-2 ConvTranspose2d layer
+// =================================================================================================
+struct S2Bwd {
+    int B, H, W, OH, OW;     // layer input map H x W (the "small" map), output map OH x OW
+    int tiles_x, tiles_y, total_tiles;
+    const float* g;          // (B, COUT, OH, OW) masked upstream gradient (or dL/dy for the last layer)
+    const float* yout;       // (B, COUT, OH, OW) raw forward output of this layer (BN_BWD transform), or nullptr
+    BnDesc bn_out;           // BN_BWD descriptor of this layer's BatchNorm, or BN_NONE
+    const float* ain;        // (B, CIN, H, W) raw output of the producer layer (this layer's input before BN+ReLU)
+    BnDesc bn_in;            // BN_SAVED descriptor of the producer's BatchNorm, or BN_NONE (plain input)
+    const float* w;          // (CIN, COUT, KH, KW)
+    float* gin;              // (B, CIN, H, W) gradient wrt the producer's raw output side: masked by its ReLU
+    double* stats_in;        // producer's [CIN][4] sums (slots 2,3), or nullptr when bn_in is BN_NONE
+    double* wacc;            // fp64 accumulator of dW
+    BnGradOut bg;            // BatchNorm parameter gradients of this layer (published by block 0)
+};
+
+// Tile: TPY x TPX input pixels per pass, one pixel per thread per ci-group.
+//   threads = TPY*TPX*CG, CG = CIN / CT ci-groups (each thread owns CT input channels)
+template <int CIN, int CT, int COUT, int KH, int KW, int TPX, int TPY>
+__global__ void __launch_bounds__(256) k_s2_bwd(S2Bwd a) {
+    constexpr int CG = CIN / CT;
+    static_assert(TPX * TPY * CG == 256, "256 threads");
+    constexpr int LW = 2 * TPX + KW - 2;   // staged gy tile width
+    constexpr int LH = 2 * TPY + KH - 2;
+    constexpr int LWH = (LW + 1) / 2;      // even and odd columns are kept in separate half-rows, so the
+    constexpr int LWP = 2 * LWH + 1;       // stride-2 patch reads of a wave are contiguous (no bank conflicts)
+    constexpr int NACC = CT * COUT * KH * KW;
+    __shared__ float tile[COUT * LH * LWP];
+    __shared__ float4 cout4[COUT];
+    __shared__ float4 cin4[CIN];
+    __shared__ float redf[4 * (NACC + 2 * CT)];
+    __shared__ __attribute__((aligned(16))) float wl[COUT * KH * KW * CIN];  // [co][ky][kx][ci]
+
+    for (int e = threadIdx.x; e < COUT * KH * KW * CIN; e += 256) {
+        const int ci = e % CIN, tap = e / CIN;  // tap = (co*KH + ky)*KW + kx
+        wl[e] = a.w[(size_t)ci * COUT * KH * KW + tap];
+    }
+    bn_consts(a.bn_out, cout4, false);
+    bn_consts(a.bn_in, cin4, false);
+    if (blockIdx.x == 0 && a.bg.stats) {
+        for (int c = threadIdx.x; c < a.bg.C; c += 256) {
+            a.bg.beta_acc[c] = a.bg.stats[4 * c + 2] * a.bg.scale;
+            a.bg.gamma_acc[c] = a.bg.stats[4 * c + 3] * a.bg.scale;
+        }
+    }
+
+    // ci-group of this thread; wave-uniform (a wave never straddles groups), so weights stay scalar
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / (TPX * TPY));
+    const int pix = threadIdx.x - grp * (TPX * TPY);
+    const int ly = pix / TPX, lx = pix - ly * TPX;
+    const int tiles = a.tiles_x * a.tiles_y;
+
+    float dw[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) dw[i] = 0.f;
+    float d1[CT], d2[CT];
+#pragma unroll
+    for (int i = 0; i < CT; i++) d1[i] = d2[i] = 0.f;
+
+    for (int t = blockIdx.x; t < a.total_tiles; t += gridDim.x) {
+        const int b = t / tiles;
+        const int tt = t - b * tiles;
+        const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+        const int y0 = ty * TPY, x0 = tx * TPX;
+        __syncthreads();  // previous tile fully consumed (also orders the bn_consts writes)
+        // ---- stage gy[co][2*y0 .. +LH)[2*x0 .. +LW) with the BatchNorm-backward transform
+        for (int e = threadIdx.x; e < COUT * LH * LW; e += 256) {
+            const int co = e / (LH * LW);
+            const int r = e - co * (LH * LW);
+            const int yy = r / LW, xx = r - yy * LW;
+            const int gy_ = 2 * y0 + yy, gx_ = 2 * x0 + xx;
+            float v = 0.f;
+            if (gy_ < a.OH && gx_ < a.OW) {
+                const size_t off = ((size_t)(b * COUT + co) * a.OH + gy_) * a.OW + gx_;
+                v = a.g[off];
+                if (a.bn_out.mode == BN_BWD) {
+                    const float4 k = cout4[co];
+                    v = k.y * v - k.z - (a.yout[off] - k.x) * k.w;
+                }
+            }
+            tile[(co * LH + yy) * LWP + (xx & 1) * LWH + (xx >> 1)] = v;
+        }
+        __syncthreads();
+        const int y = y0 + ly, x = x0 + lx;
+        if (y < a.H && x < a.W) {
+            // this thread's input activations (BN + ReLU of the producer's raw output)
+            float av[CT], yraw[CT];
+#pragma unroll
+            for (int c = 0; c < CT; c++) {
+                const int ci = grp * CT + c;
+                const size_t off = ((size_t)(b * CIN + ci) * a.H + y) * a.W + x;
+                yraw[c] = a.ain[off];
+                av[c] = yraw[c];
+                if (a.bn_in.mode != BN_NONE) {
+                    const float4 k = cin4[ci];
+                    av[c] = fmaxf(0.f, fmaf(yraw[c] - k.x, k.y, k.z));
+                }
+            }
+            float ga[CT];
+#pragma unroll
+            for (int c = 0; c < CT; c++) ga[c] = 0.f;
+#pragma unroll
+            for (int co = 0; co < COUT; co++) {
+#pragma unroll
+                for (int ky = 0; ky < KH; ky++) {
+#pragma unroll
+                    for (int kx = 0; kx < KW; kx++) {
+                        const float p = tile[(co * LH + 2 * ly + ky) * LWP + (kx & 1) * LWH + lx + (kx >> 1)];
+                        const float* wp = &wl[((co * KH + ky) * KW + kx) * CIN + grp * CT];
+#pragma unroll
+                        for (int c = 0; c < CT; c++) {
+                            const float wv = wp[c];
+                            ga[c] = fmaf(p, wv, ga[c]);
+                            dw[((c * COUT + co) * KH + ky) * KW + kx] =
+                                fmaf(av[c], p, dw[((c * COUT + co) * KH + ky) * KW + kx]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CT; c++) {
+                const int ci = grp * CT + c;
+                const size_t off = ((size_t)(b * CIN + ci) * a.H + y) * a.W + x;
+                float gv = ga[c];
+                if (a.bn_in.mode != BN_NONE) {
+                    const float4 k = cin4[ci];
+                    const float d = yraw[c] - k.x;
+                    gv = fmaf(d, k.y, k.z) > 0.f ? gv : 0.f;
+                    d1[c] += gv;
+                    d2[c] = fmaf(gv, d * k.w, d2[c]);
+                }
+                a.gin[off] = gv;
+            }
+        }
+    }
+
+    // ---- reduce accumulators over the block: wave shuffle, then the 4 waves through LDS
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NRED = NACC + 2 * CT;
+    // all lanes of a wave belong to one ci-group when TPX*TPY >= 64
+    static_assert((TPX * TPY) % 64 == 0, "a wave must not straddle ci-groups");
+#pragma unroll
+    for (int i = 0; i < NACC; i++) {
+        const float s = wave_sum_f(dw[i]);
+        if (lane == 0) redf[wv * NRED + i] = s;
+    }
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+        const float s1 = wave_sum_f(d1[c]), s2 = wave_sum_f(d2[c]);
+        if (lane == 0) {
+            redf[wv * NRED + NACC + 2 * c] = s1;
+            redf[wv * NRED + NACC + 2 * c + 1] = s2;
+        }
+    }
+    __syncthreads();
+    constexpr int WPG = (TPX * TPY) / 64;  // waves per ci-group
+    for (int i = threadIdx.x; i < CG * NRED; i += 256) {
+        const int gsel = i / NRED, j = i - gsel * NRED;
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < WPG; q++) s += (double)redf[(gsel * WPG + q) * NRED + j];
+        if (j < NACC) {
+            // j = ((c*COUT + co)*KH + ky)*KW + kx  ->  global weight index with ci = gsel*CT + c
+            const int c = j / (COUT * KH * KW), rest = j - c * (COUT * KH * KW);
+            const int ci = gsel * CT + c;
+            atomicAdd(&a.wacc[(size_t)ci * COUT * KH * KW + rest], s);
+        } else if (a.stats_in) {
+            const int jj = j - NACC;
+            const int ci = gsel * CT + (jj >> 1);
+            atomicAdd(&a.stats_in[4 * ci + 2 + (jj & 1)], s);
+        }
+    }
+}
+
+}  // namespace cae

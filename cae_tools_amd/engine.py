@@ -76,7 +76,7 @@ class EnginePlan:
 
 class HipEngine(EnginePlan):
 
-    def __init__(self, spec, fc_size, latent_size, max_batch, device=None, graph=True):
+    def __init__(self, spec, fc_size, latent_size, max_batch, device=None, graph=True, specialised=True):
         if not torch.cuda.is_available():
             raise CaeError("cae_tools_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
                            "there is no CPU fallback")
@@ -97,6 +97,7 @@ class HipEngine(EnginePlan):
                                 ws_ptr, self.workspace_bytes))
         check(self.lib.cae_set_stream(self.handle, self.stream.cuda_stream))
         check(self.lib.cae_set_graph_mode(self.handle, 1 if graph else 0))
+        check(self.lib.cae_set_kernel_mode(self.handle, 1 if specialised else 0))
         torch.cuda.synchronize(self.device)
         self.num_batches_tracked = 0
         self.adam_steps = 0

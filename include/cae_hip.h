@@ -93,6 +93,10 @@ int cae_set_stream(cae_engine* e, void* hip_stream);
 /* 1: replay each step from a captured hipGraph (default); 0: plain launches */
 int cae_set_graph_mode(cae_engine* e, int enabled);
 
+/* 1 (default): use the specialised kernels where a layer is eligible; 0: shape-generic kernels
+ * everywhere (kept as an on-device cross-check of the specialised ones). */
+int cae_set_kernel_mode(cae_engine* e, int specialised);
+
 /* torch.optim.Adam(lr, betas, eps, weight_decay) with L2 decay added to the gradient
  * (conv_ae_model.py:310). */
 int cae_set_hyper(cae_engine* e, double lr, double beta1, double beta2, double eps, double weight_decay);

@@ -22,10 +22,10 @@ from helpers import (MODEL_CASES, GoldenCase, assert_close_as_reference, bn_bias
 pytestmark = pytest.mark.gpu
 
 
-def _engine(case, graph=True, max_batch=None):
+def _engine(case, graph=True, max_batch=None, specialised=True):
     from cae_tools_amd.engine import HipEngine
     eng = HipEngine(case.spec, case.meta["fc"], case.meta["latent"],
-                    max_batch=max_batch or max(8, case.meta["batch"]), graph=graph)
+                    max_batch=max_batch or max(8, case.meta["batch"]), graph=graph, specialised=specialised)
     eng.load_state(case.group("init/enc/"), case.group("init/dec/"))
     eng.set_hyper(lr=case.meta["lr"], weight_decay=case.meta["weight_decay"])
     return eng
@@ -44,10 +44,11 @@ def _dataset(eng, case):
     return x, t
 
 
+@pytest.mark.parametrize("specialised", [False, True])
 @pytest.mark.parametrize("name", MODEL_CASES)
-def test_eval_forward(name):
+def test_eval_forward(name, specialised):
     case = GoldenCase(name)
-    eng = _engine(case)
+    eng = _engine(case, specialised=specialised)
     y = eng.score(torch.from_numpy(case.x).cuda()).cpu().numpy()
     ref = _oracle(case).eval_forward(torch.from_numpy(case.x)).numpy()
     assert np.abs(y - ref).max() <= 1e-5
@@ -55,11 +56,11 @@ def test_eval_forward(name):
     np.testing.assert_allclose(projections(y, 77), case["eval0/y_proj"], rtol=0, atol=2e-3)
 
 
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph,specialised", [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("name", MODEL_CASES)
-def test_train_forward_backward(name, graph):
+def test_train_forward_backward(name, graph, specialised):
     case = GoldenCase(name)
-    eng = _engine(case, graph=graph)
+    eng = _engine(case, graph=graph, specialised=specialised)
     _dataset(eng, case)
     b = case.meta["batch"]
     slot = eng.forward_backward(0, None, 0, b, b)
