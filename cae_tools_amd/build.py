@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libcae_hip.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["kernels_generic.h", "kernels_s2.h"]
+HEADERS = ["kernels_generic.h", "kernels_s2.h", "kernels_gemm.h"]
 ARCH = "gfx950"
 
 
@@ -34,7 +34,7 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-cuda-compat", "-Wno-pass-failed",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB + ".tmp"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

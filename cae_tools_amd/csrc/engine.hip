@@ -14,6 +14,7 @@
 #include "cae_hip.h"
 #include "kernels_generic.h"
 #include "kernels_s2.h"
+#include "kernels_gemm.h"
 
 using namespace cae;
 
@@ -190,6 +191,7 @@ Epi epi_plain(float* out) {
 size_t lds_bytes(int c1, int c2) { return 4 * sizeof(double) + (size_t)(c1 + c2 + 1) * sizeof(float4); }
 
 int grid1(int64_t n) { return (int)((n + 255) / 256); }
+size_t gemm_lds(int channels) { return (4 * 256 + 128) * sizeof(float) + (size_t)(channels + 1) * sizeof(float4); }
 
 // positions per block for k_wgrad: aim for ~2048 blocks in total, at least 256 positions each
 int wgrad_ppb(int64_t positions, int64_t nweights) {
@@ -336,10 +338,27 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
         const float* in = e->fptr(P.act_off);
         for (int i = 0; i < 4; i++) {
             const FcLayer& F = e->fc[i];
-            ProfScope _p(e, "linear_fwd", i, f4((double)B * (F.nin + F.nout) + (double)F.nin * F.nout));
-            hipLaunchKernelGGL(k_lin_fwd, dim3(grid1((int64_t)B * F.nout)), dim3(256), lds_bytes(i == 0 ? P.cout : 0, 0),
-                               s, B, F.nin, F.nout, in, i == 0 ? bni : bn_none(), hw, e->params + F.w_off,
-                               e->params + F.b_off, F.relu ? 1 : 0, e->fptr(F.act_off));
+            ProfScope _p(e, e->use_s2 ? "linear_fwd_mfma" : "linear_fwd", i, f4((double)B * (F.nin + F.nout) + (double)F.nin * F.nout));
+            if (e->use_s2) {
+                GemmArgs ga;
+                memset(&ga, 0, sizeof ga);
+                ga.M = B; ga.N = F.nout; ga.K = F.nin;
+                ga.A = in; ga.sa_m = F.nin; ga.sa_k = 1;
+                ga.B = e->params + F.w_off; ga.sb_k = 1; ga.sb_n = F.nin;   // B[k][n] = W[n][k]
+                ga.C = e->fptr(F.act_off); ga.sc_m = F.nout; ga.sc_n = 1;
+                ga.epi = GE_STORE;
+                ga.bias = e->params + F.b_off;
+                ga.relu = F.relu ? 1 : 0;
+                ga.bn_a = i == 0 ? bni : bn_none();
+                ga.hw_a = hw;
+                ga.bn_c = bn_none();
+                const int tiles = ((B + 15) / 16) * ((F.nout + 15) / 16);
+                hipLaunchKernelGGL(k_gemm16, dim3(tiles), dim3(256), gemm_lds(i == 0 ? P.cout : 0), s, ga);
+            } else {
+                hipLaunchKernelGGL(k_lin_fwd, dim3(grid1((int64_t)B * F.nout)), dim3(256), lds_bytes(i == 0 ? P.cout : 0, 0),
+                                   s, B, F.nin, F.nout, in, i == 0 ? bni : bn_none(), hw, e->params + F.w_off,
+                                   e->params + F.b_off, F.relu ? 1 : 0, e->fptr(F.act_off));
+            }
             in = e->fptr(F.act_off);
         }
     }
@@ -527,6 +546,54 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             const float* gout = e->fptr(F.grad_off);
             const float* in = i == 0 ? e->fptr(P.act_off) : e->fptr(e->fc[i - 1].act_off);
             BnDesc bni = i == 0 ? bn_of(e, P, BN_SAVED, 0, 0) : bn_none();
+            if (e->use_s2) {
+                {   // dW[o][i] = sum_b gout[b][o] * in[b][i], db[o] = sum_b gout[b][o]  (ones column)
+                    ProfScope _p(e, "linear_wgrad_mfma", i, f4((double)B * (F.nin + F.nout)) + 8.0 * F.nin * F.nout);
+                    GemmArgs ga;
+                    memset(&ga, 0, sizeof ga);
+                    ga.M = F.nout; ga.N = F.nin + 1; ga.K = B;
+                    ga.A = gout; ga.sa_m = 1; ga.sa_k = F.nout;       // A[m=o][k=b] = gout[b][o]
+                    ga.B = in; ga.sb_k = F.nin; ga.sb_n = 1;          // B[k=b][n=i] = in[b][i]
+                    ga.epi = GE_ACC64;
+                    ga.accW = acc + F.w_off; ga.accB = acc + F.b_off; ga.ones_col = 1;
+                    if (i == 0) {
+                        // its input carries the BatchNorm+ReLU transform on the B side; tiny (C*y*x x fc):
+                        // the generic kernel handles it
+                        hipLaunchKernelGGL(k_lin_wgrad, dim3(grid1((int64_t)F.nin * F.nout)), dim3(256),
+                                           lds_bytes(P.cout, 0), s, B, F.nin, F.nout, gout, in, bni, hw,
+                                           acc + F.w_off, acc + F.b_off);
+                    } else {
+                        const int tiles = ((ga.M + 15) / 16) * ((ga.N + 15) / 16);
+                        hipLaunchKernelGGL(k_gemm16, dim3(tiles), dim3(256), gemm_lds(0), s, ga);
+                    }
+                }
+                {   // gin[b][i] = mask( sum_o gout[b][o] * W[o][i] )
+                    ProfScope _p(e, "linear_dgrad_mfma", i, f4((double)B * (2.0 * F.nin + F.nout) + (double)F.nin * F.nout));
+                    GemmArgs ga;
+                    memset(&ga, 0, sizeof ga);
+                    ga.M = B; ga.N = F.nin; ga.K = F.nout;
+                    ga.A = gout; ga.sa_m = F.nout; ga.sa_k = 1;
+                    ga.B = e->params + F.w_off; ga.sb_k = F.nin; ga.sb_n = 1;   // B[k=o][n=i] = W[o][i]
+                    ga.sc_m = F.nin; ga.sc_n = 1;
+                    size_t lds = gemm_lds(0);
+                    if (i > 0) {
+                        const FcLayer& G = e->fc[i - 1];
+                        ga.C = e->fptr(G.grad_off);
+                        ga.epi = G.relu ? GE_RELU_MASK : GE_STORE;
+                        ga.H = e->fptr(G.act_off);
+                    } else {
+                        ga.C = e->fptr(P.grad_off);
+                        ga.epi = GE_BN_MASK;
+                        ga.H = e->fptr(P.act_off);
+                        ga.bn_c = bni; ga.hw_c = hw;
+                        ga.stats_c = e->bn_stats(P.bn_index);
+                        lds = gemm_lds(P.cout);
+                    }
+                    const int tiles = ((ga.M + 15) / 16) * ((ga.N + 15) / 16);
+                    hipLaunchKernelGGL(k_gemm16, dim3(tiles), dim3(256), lds, s, ga);
+                }
+                continue;
+            }
             {
                 ProfScope _p(e, "linear_wgrad", i, f4((double)B * (F.nin + F.nout)) + 8.0 * F.nin * F.nout);
                 hipLaunchKernelGGL(k_lin_wgrad, dim3(grid1((int64_t)F.nin * F.nout)), dim3(256),

@@ -1,0 +1,144 @@
+// kernels_gemm.h — small fp32 GEMM on the CDNA4 matrix cores for the Linear layers
+// (encoder.py:54-58, decoder.py:31-35): forward, input gradient and weight gradient are all
+// C[M,N] = A[M,K] * B[K,N] with different strides.
+//
+// The matrices are tiny (M = batch 64, N,K <= 576) and L2-resident, so the kernel is built for
+// latency, not for operand reuse: one wave owns one 16x16 tile of C and walks K with
+// v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate), operands fetched straight from
+// global memory into the MFMA lane layout (lane l: A[row l&15][k0 + (l>>4)], B[k0 + (l>>4)][col l&15]).
+// 4 waves per workgroup; grid = ceil(tiles / 4).
+#pragma once
+#include "kernels_generic.h"
+
+namespace cae {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum GemmEpi : int {
+    GE_STORE = 0,        // C = acc (+bias[n]) (relu)
+    GE_RELU_MASK = 1,    // C = H[m][n] > 0 ? acc : 0        (gradient through the producer's ReLU)
+    GE_BN_MASK = 2,      // C = bnrelu(Y[m][n]) > 0 ? acc : 0, D1/D2 sums of channel n / hw
+    GE_ACC64 = 3         // double accumulator: accW[m][n] = acc, column N-1 (ones) -> accB[m]
+};
+
+struct GemmArgs {
+    int M, N, K;
+    const float* A; long long sa_m, sa_k;
+    const float* B; long long sb_k, sb_n;
+    float* C; long long sc_m, sc_n;
+    int epi;
+    const float* bias;     // GE_STORE: per n, or nullptr
+    int relu;              // GE_STORE
+    const float* H;        // GE_RELU_MASK / GE_BN_MASK: same indexing as C
+    BnDesc bn_a;           // BatchNorm+ReLU applied to A elements, channel = k / hw_a (BN_NONE: identity)
+    int hw_a;
+    BnDesc bn_c;           // GE_BN_MASK: BN_SAVED descriptor, channel = n / hw_c
+    int hw_c;
+    double* stats_c;       // GE_BN_MASK: [C][4] sums (slots 2,3)
+    double* accW; double* accB;  // GE_ACC64; B's last column (n == N-1) is the constant 1 when ones_col
+    int ones_col;
+};
+
+// One workgroup = 4 waves = one 16x16 tile of C; the waves split K into 4 contiguous chunks
+// (split-K inside the workgroup, combined through LDS), so even a 64x128x576 product keeps
+// every k-chain short.  Loads are issued 8 k-steps at a time ahead of their MFMAs.
+__global__ void __launch_bounds__(256) k_gemm16(GemmArgs g) {
+    extern __shared__ double lds_d[];
+    float* part = reinterpret_cast<float*>(lds_d);              // [4 waves][256] partial tiles
+    float* lstat = part + 4 * 256;                              // [<=64 channels][2] GE_BN_MASK sums
+    float4* ca = reinterpret_cast<float4*>(lstat + 128);
+    float4* cc = ca + (g.bn_a.mode ? g.bn_a.C : 0);
+    bn_consts(g.bn_a, ca, blockIdx.x == 0);
+    bn_consts(g.bn_c, cc, false);
+    if (threadIdx.x < 128) lstat[threadIdx.x] = 0.f;
+    __syncthreads();
+
+    const int tiles_n = (g.N + 15) >> 4;
+    const int tile = blockIdx.x;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int am = tm * 16 + r;   // A row fetched by this lane
+    const int bn = tn * 16 + r;   // B column fetched by this lane
+    const bool am_ok = am < g.M, bn_ok = bn < g.N;
+    const bool b_ones = g.ones_col && bn == g.N - 1;
+    const float* ap = g.A + (long long)am * g.sa_m;
+    const float* bp = g.B + (long long)bn * g.sb_n;
+
+    // this wave's K chunk, in whole k-steps of 4
+    const int steps = (g.K + 3) >> 2;
+    const int per = (steps + 3) >> 2;
+    const int s0 = wv * per, s1 = min(steps, s0 + per);
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int st = s0; st < s1; st += 8) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = (st + u) * 4 + q;
+            const bool k_ok = (st + u) < s1 && k < g.K;
+            a[u] = (am_ok && k_ok) ? ap[(long long)k * g.sa_k] : 0.f;
+            b[u] = (bn_ok && k_ok) ? (b_ones ? 1.0f : bp[(long long)k * g.sb_k]) : 0.f;
+            if (g.bn_a.mode != BN_NONE && am_ok && k_ok) {
+                const float4 c4 = ca[k / g.hw_a];
+                a[u] = fmaxf(0.f, fmaf(a[u] - c4.x, c4.y, c4.z));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) part[wv * 256 + j * 64 + lane] = acc[j];
+    __syncthreads();
+    if (wv != 0) {
+        if (g.epi != GE_BN_MASK) return;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            acc[j] = part[j * 64 + lane] + part[256 + j * 64 + lane] + part[512 + j * 64 + lane] + part[768 + j * 64 + lane];
+    }
+
+    // C/D layout of the 16x16 MFMA: register j of lane l is C[row 4*(l>>4) + j][col l&15]
+    const int cn = tn * 16 + r;
+    if (wv == 0 && cn < g.N) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int cm = tm * 16 + q * 4 + j;
+            if (cm >= g.M) continue;
+            float v = acc[j];
+            const long long off = (long long)cm * g.sc_m + (long long)cn * g.sc_n;
+            if (g.epi == GE_STORE) {
+                if (g.bias) v += g.bias[cn];
+                if (g.relu) v = fmaxf(v, 0.f);
+                g.C[off] = v;
+            } else if (g.epi == GE_RELU_MASK) {
+                g.C[off] = g.H[off] > 0.f ? v : 0.f;
+            } else if (g.epi == GE_BN_MASK) {
+                const int ch = cn / g.hw_c;
+                const float4 c4 = cc[ch];
+                const float d = g.H[off] - c4.x;
+                const float gm = fmaf(d, c4.y, c4.z) > 0.f ? v : 0.f;
+                g.C[off] = gm;
+                atomicAdd(&lstat[2 * ch], gm);              // LDS atomics: a tile spans <= 16 channels
+                atomicAdd(&lstat[2 * ch + 1], gm * (d * c4.w));
+            } else {  // GE_ACC64
+                if (g.ones_col && cn == g.N - 1) {
+                    g.accB[cm] = (double)v;
+                } else {
+                    g.accW[(long long)cm * (g.N - (g.ones_col ? 1 : 0)) + cn] = (double)v;
+                }
+            }
+        }
+    }
+    if (g.epi == GE_BN_MASK) {
+        __syncthreads();
+        const int c0 = (tn * 16) / g.hw_c, c1 = min(g.bn_c.C - 1, (tn * 16 + 15) / g.hw_c);
+        const int i = threadIdx.x;
+        if (i < 2 * (c1 - c0 + 1)) {
+            const int ch = c0 + (i >> 1);
+            atomicAdd(&g.stats_c[4 * ch + 2 + (i & 1)], (double)lstat[2 * ch + (i & 1)]);
+        }
+    }
+}
+
+}  // namespace cae
