@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libcae_hip.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["kernels_generic.h", "kernels_s2.h", "kernels_gemm.h"]
+HEADERS = ["kernels_generic.h", "kernels_s2.h", "kernels_gemm.h", "kernels_igemm.h"]
 ARCH = "gfx950"
 
 

@@ -15,6 +15,7 @@
 #include "kernels_generic.h"
 #include "kernels_s2.h"
 #include "kernels_gemm.h"
+#include "kernels_igemm.h"
 
 using namespace cae;
 
@@ -324,6 +325,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
         if (a.train) {
             ep.kind = EPI_STATS;
             ep.stats = e->bn_stats(L.bn_index);
+            ep.stats_C = L.cout;
         }
         dim3 grid(grid1((int64_t)B * L.hout * L.wout), L.cout);
         ProfScope _p(e, a.train ? "enc_conv_fwd" : "enc_conv_eval", (int)l, f4((double)B * (L.in_elems() + L.out_elems())));
@@ -382,6 +384,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             if (a.train) {
                 ep.kind = EPI_STATS;
                 ep.stats = e->bn_stats(L.bn_index);
+                ep.stats_C = L.cout;
             }
         } else {
             memset(&ep, 0, sizeof ep);
@@ -426,6 +429,20 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             ProfScope _p(e, last ? (a.train ? "s2_convt_last_fwd_loss" : "s2_convt_last_eval") : (a.train ? "s2_convt_fwd" : "s2_convt_eval"), (int)l,
                          f4((double)B * (L.in_elems() + L.out_elems() * (last && (a.train || a.want_loss) ? 2.0 : 1.0))));
             s2_fwd_dispatch(L, f, s);
+            continue;
+        }
+        if (e->use_s2 && !last && L.stride == 2 && L.kh <= 4 && L.kw <= 4) {
+            IgFwd f;
+            memset(&f, 0, sizeof f);
+            f.B = B; f.Cin = L.cin; f.H = L.hin; f.W = L.win; f.Cout = L.cout; f.OH = L.hout; f.OW = L.wout;
+            f.KH = L.kh; f.KW = L.kw; f.QH = (L.hout + 1) / 2; f.QW = (L.wout + 1) / 2;
+            f.in = small.p; f.bn_in = bns; f.w = e->params + L.w_off; f.bias = e->params + L.b_off;
+            f.out = ep.out; f.stats = a.train ? ep.stats : nullptr;
+            const int mtiles = (B * f.QH * f.QW + 15) / 16;
+            f.tiles_per_wave = mtiles >= 4096 ? 4 : (mtiles >= 1024 ? 2 : 1);
+            dim3 grid((mtiles + 4 * f.tiles_per_wave - 1) / (4 * f.tiles_per_wave), 4, (L.cout + 15) / 16);
+            ProfScope _p(e, a.train ? "ig_convt_fwd" : "ig_convt_eval", (int)l, f4((double)B * (L.in_elems() + L.out_elems())));
+            hipLaunchKernelGGL(k_ig_fwd_s2, grid, dim3(256), 32 * sizeof(float) + (size_t)(L.cin + 1) * sizeof(float4), s, f);
             continue;
         }
         dim3 grid(grid1((int64_t)B * L.hout * L.wout), L.cout);
@@ -498,6 +515,59 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             s2_bwd_dispatch(L, f, s);
             continue;
         }
+        if (e->use_s2) {
+            {
+                IgWgrad f;
+                memset(&f, 0, sizeof f);
+                f.B = B; f.Cin = L.cin; f.H = L.hin; f.W = L.win; f.Cout = L.cout; f.OH = L.hout; f.OW = L.wout;
+                f.KH = L.kh; f.KW = L.kw; f.S = L.stride;
+                f.ain = ain.p; f.bn_in = bna; f.g = gy.p; f.yout = gy.q; f.bn_out = bng;
+                f.wacc = acc + L.w_off;
+                if (L.has_bn) {
+                    f.bg.stats = e->bn_stats(L.bn_index);
+                    f.bg.gamma_acc = acc + L.gamma_off;
+                    f.bg.beta_acc = acc + L.beta_off;
+                    f.bg.C = L.cout;
+                    f.bg.scale = 1.0;
+                }
+                const int tiles = ((L.cin + 15) / 16) * ((L.cout * L.kh * L.kw + 15) / 16);
+                const int steps = (B * L.hin * L.win + 3) / 4;
+                int chunks = 1024 / tiles;
+                if (chunks < 1) chunks = 1;
+                int per = (steps + chunks - 1) / chunks;
+                per = (per + 31) / 32 * 32;
+                chunks = (steps + per - 1) / per;
+                f.ksteps_per_block = per;
+                ProfScope _p(e, "ig_convt_wgrad", l, f4((double)B * (L.in_elems() + L.out_elems() * (last ? 1.0 : 2.0))));
+                hipLaunchKernelGGL(k_ig_wgrad, dim3(tiles, chunks), dim3(256),
+                                   1024 * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4), s, f);
+            }
+            {
+                IgDgrad f;
+                memset(&f, 0, sizeof f);
+                f.B = B; f.Cin = L.cin; f.H = L.hin; f.W = L.win; f.Cout = L.cout; f.OH = L.hout; f.OW = L.wout;
+                f.KH = L.kh; f.KW = L.kw; f.S = L.stride;
+                f.g = gy.p; f.yout = gy.q; f.bn_out = bng; f.w = e->params + L.w_off;
+                if (l == 0) {
+                    f.gin = e->fptr(e->fc[3].grad_off);
+                } else {
+                    const ConvLayer& P = e->dec[l - 1];
+                    f.gin = e->fptr(P.grad_off);
+                    f.yprev = e->fptr(P.act_off);
+                    f.bn_prev = bn_of(e, P, BN_SAVED, 0, 0);
+                    f.stats_prev = e->bn_stats(P.bn_index);
+                }
+                const int mtiles = (B * L.hin * L.win + 15) / 16;
+                f.tiles_per_wave = mtiles >= 4096 ? 4 : (mtiles >= 1024 ? 2 : 1);
+                dim3 grid((mtiles + 4 * f.tiles_per_wave - 1) / (4 * f.tiles_per_wave), (L.cin + 15) / 16);
+                const size_t lds = 32 * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4) +
+                                   (size_t)L.cout * L.kh * L.kw * sizeof(int);
+                ProfScope _p(e, "ig_convt_dgrad", l,
+                             f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));
+                hipLaunchKernelGGL(k_ig_dgrad, grid, dim3(256), lds, s, f);
+            }
+            continue;
+        }
         // weight gradient (+ BN parameter gradients of this layer)
         {
             const int64_t nw = (int64_t)L.cin * L.cout * L.kh * L.kw;
@@ -528,6 +598,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 ep = epi_plain(e->fptr(P.grad_off));
                 ep.kind = EPI_MASKSTATS;
                 ep.stats = e->bn_stats(P.bn_index);
+                ep.stats_C = P.cout;
                 ep.yprev = e->fptr(P.act_off);
                 bne = bn_of(e, P, BN_SAVED, 0, 0);
             }
@@ -654,6 +725,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             Epi ep = epi_plain(e->fptr(P.grad_off));
             ep.kind = EPI_MASKSTATS;
             ep.stats = e->bn_stats(P.bn_index);
+            ep.stats_C = P.cout;
             ep.yprev = e->fptr(P.act_off);
             BnDesc bne = bn_of(e, P, BN_SAVED, 0, 0);
             dim3 grid(grid1((int64_t)B * L.hin * L.win), L.cin);
@@ -859,7 +931,7 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
     auto reg_bn = [&](const ConvLayer& L) {
         if (!L.has_bn) return;
         e->bn_channels[L.bn_index] = L.cout;
-        e->bn_stat_off[L.bn_index] = carve(top, (int64_t)L.cout * 4 * sizeof(double));
+        e->bn_stat_off[L.bn_index] = carve(top, (int64_t)kStatShards * L.cout * 4 * sizeof(double));
         if (L.cout > e->max_channels) e->max_channels = L.cout;
     };
     for (auto& L : e->enc) reg_bn(L);
@@ -1076,7 +1148,7 @@ int64_t cae_debug_read(cae_engine* e, const char* what, int index, void* host_ou
     } else if (w == "bn_stats") {
         if (index < 0 || index >= e->n_bn) return fail(CAE_ERR_ARG, "bn index out of range");
         src = e->bn_stats(index);
-        n = (int64_t)e->bn_channels[index] * 4;
+        n = (int64_t)kStatShards * e->bn_channels[index] * 4;
         esz = 8;
     } else {
         return fail(CAE_ERR_ARG, "unknown tensor '%s'", what);

@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(256) k_gemm16(GemmArgs g) {
         const int i = threadIdx.x;
         if (i < 2 * (c1 - c0 + 1)) {
             const int ch = c0 + (i >> 1);
-            atomicAdd(&g.stats_c[4 * ch + 2 + (i & 1)], (double)lstat[2 * ch + (i & 1)]);
+            atomicAdd(&g.stats_c[((size_t)(blockIdx.x & (kStatShards - 1)) * g.bn_c.C + ch) * 4 + 2 + (i & 1)],
+                      (double)lstat[2 * ch + (i & 1)]);
         }
     }
 }

@@ -18,6 +18,11 @@
 
 namespace cae {
 
+// BatchNorm sum accumulators are kept in kStatShards copies, [shard][C][4]; producers add into the
+// copy picked by their block index (same-address fp64 atomics serialise at the memory side),
+// consumers add the copies up in bn_consts.
+constexpr int kStatShards = 8;
+
 struct StepState {
     long long batch_start;  // first position in the permutation of the current batch
     int loss_slot;          // where this step's loss is accumulated
@@ -36,7 +41,7 @@ enum BnMode : int {
 struct BnDesc {
     int mode;
     int C;
-    const double* stats;  // [C][4]: sum y, sum y^2, sum g, sum g*xhat
+    const double* stats;  // [kStatShards][C][4]: sum y, sum y^2, sum g, sum g*xhat
     const float* gamma;
     const float* beta;
     float* rmean;
@@ -62,7 +67,8 @@ enum EpiKind : int { EPI_PLAIN = 0, EPI_STATS = 1, EPI_MASKSTATS = 2, EPI_SIGMSE
 struct Epi {
     int kind;
     float* out;           // PLAIN/STATS: raw output; MASKSTATS: masked gradient; SIGMSE: dL/d(pre-sigmoid)
-    double* stats;        // STATS: [C][4] slots 0,1; MASKSTATS: slots 2,3
+    double* stats;        // STATS: [shards][C][4] slots 0,1; MASKSTATS: slots 2,3
+    int stats_C;          // channel count of that table
     const float* yprev;   // MASKSTATS: raw forward output at the same element
     const float* target;  // SIGMSE / SIGOUT(optional)
     const int* perm;
@@ -108,7 +114,11 @@ __device__ __forceinline__ void bn_consts(const BnDesc& d, float4* out, bool des
     for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
         float mean, invstd;
         if (d.mode == BN_BATCH) {
-            const double s1 = d.stats[4 * c], s2 = d.stats[4 * c + 1];
+            double s1 = 0.0, s2 = 0.0;
+            for (int sh = 0; sh < kStatShards; sh++) {
+                s1 += d.stats[((size_t)sh * d.C + c) * 4];
+                s2 += d.stats[((size_t)sh * d.C + c) * 4 + 1];
+            }
             const double m = s1 / d.count;
             double var = s2 / d.count - m * m;
             var = var < 0.0 ? 0.0 : var;
@@ -130,7 +140,11 @@ __device__ __forceinline__ void bn_consts(const BnDesc& d, float4* out, bool des
         }
         const float scale = d.gamma[c] * invstd;
         if (d.mode == BN_BWD) {
-            const double dbeta = d.stats[4 * c + 2], dgamma = d.stats[4 * c + 3];
+            double dbeta = 0.0, dgamma = 0.0;
+            for (int sh = 0; sh < kStatShards; sh++) {
+                dbeta += d.stats[((size_t)sh * d.C + c) * 4 + 2];
+                dgamma += d.stats[((size_t)sh * d.C + c) * 4 + 3];
+            }
             const float k2 = (float)((double)scale * dbeta / d.count);
             const float k3 = (float)((double)scale * (double)invstd * dgamma / d.count);
             out[c] = make_float4(mean, scale, k2, k3);
@@ -205,12 +219,13 @@ __device__ __forceinline__ void epi_block(const Epi& e, int c, const StepState* 
     const double t1 = block_sum(r1, red);
     const double t2 = (e.kind == EPI_SIGOUT) ? 0.0 : block_sum(r2, red);
     if (threadIdx.x == 0) {
+        const size_t row = ((size_t)(blockIdx.x & (kStatShards - 1)) * e.stats_C + c) * 4;
         if (e.kind == EPI_STATS) {
-            atomicAdd(&e.stats[4 * c + 0], t1);
-            atomicAdd(&e.stats[4 * c + 1], t2);
+            atomicAdd(&e.stats[row + 0], t1);
+            atomicAdd(&e.stats[row + 1], t2);
         } else if (e.kind == EPI_MASKSTATS) {
-            atomicAdd(&e.stats[4 * c + 2], t1);
-            atomicAdd(&e.stats[4 * c + 3], t2);
+            atomicAdd(&e.stats[row + 2], t1);
+            atomicAdd(&e.stats[row + 3], t2);
         } else if (e.kind == EPI_SIGMSE) {
             atomicAdd(&e.losses[st->loss_slot], t1);
             atomicAdd(&e.bias_acc[c], t2);
@@ -328,7 +343,7 @@ __global__ void __launch_bounds__(256) k_up(ConvGeom g, Src small, BnDesc bns, c
 // backward this is (dgamma = sum g*xhat, dbeta = sum g), taken from the fp64 stat sums.
 // ---------------------------------------------------------------------------------------------
 struct BnGradOut {
-    const double* stats;  // [C][4] of the BN that follows this layer, or nullptr
+    const double* stats;  // [shards][C][4] of the BN that follows this layer, or nullptr
     double* gamma_acc;
     double* beta_acc;
     int C;
@@ -346,8 +361,13 @@ __global__ void __launch_bounds__(256) k_wgrad(ConvGeom g, Src small, BnDesc bns
     bn_consts(bnb, cb, false);
     if (blockIdx.x == 0 && blockIdx.y == 0 && bg.stats) {
         for (int c = threadIdx.x; c < bg.C; c += blockDim.x) {
-            bg.beta_acc[c] = bg.stats[4 * c + 2] * bg.scale;
-            bg.gamma_acc[c] = bg.stats[4 * c + 3] * bg.scale;
+            double sb = 0.0, sg = 0.0;
+            for (int sh = 0; sh < kStatShards; sh++) {
+                sb += bg.stats[((size_t)sh * bg.C + c) * 4 + 2];
+                sg += bg.stats[((size_t)sh * bg.C + c) * 4 + 3];
+            }
+            bg.beta_acc[c] = sb * bg.scale;
+            bg.gamma_acc[c] = sg * bg.scale;
         }
     }
     __syncthreads();
@@ -455,8 +475,9 @@ __global__ void __launch_bounds__(256) k_lin_dgrad(int B, int nin, int nout, con
     const double t1 = block_sum(r1, red);
     const double t2 = block_sum(r2, red);
     if (threadIdx.x == 0) {
-        atomicAdd(&stats[4 * c + 2], t1);
-        atomicAdd(&stats[4 * c + 3], t2);
+        const size_t row = ((size_t)(blockIdx.x & (kStatShards - 1)) * bne.C + c) * 4;
+        atomicAdd(&stats[row + 2], t1);
+        atomicAdd(&stats[row + 3], t2);
     }
 }
 

@@ -1,0 +1,332 @@
+// kernels_igemm.h — implicit-GEMM kernels on the fp32 matrix cores (v_mfma_f32_16x16x4_f32) for
+// the channel-rich ConvTranspose2d layers at the head of the decoder (64->32, 32->16, 16->8 ...):
+// there the contraction is long enough (K = 64..576) to be GEMM-shaped, while the maps are tiny
+// (3x3 .. 31x31), so the operands are gathered straight from NCHW global memory (L2-resident)
+// into the MFMA lane layout — im2col exists only as address arithmetic.
+//
+//   forward, stride 2 (k_ig_fwd_s2): one GEMM per output parity class (py,px):
+//       out[(b,m,n)][co] = sum_{ci,(j,i)} a[b][ci][m-j][n-i] * W[ci][co][py+2j][px+2i]
+//       M = B*QH*QW quads, N = Cout, K = 4*Cin.  A k-step of the 16x16x4 MFMA is exactly one input
+//       channel's 2x2 neighbourhood, so a lane's tap (j,i) and its validity are loop invariants.
+//   input gradient (k_ig_dgrad):  ga[(b,y,x)][ci] = sum_{(co,ky,kx)} gy[b][co][s*y+ky][s*x+kx] * W[ci][(co,ky,kx)]
+//       M = B*H*W, N = Cin, K = Cout*kh*kw
+//   weight gradient (k_ig_wgrad): dW[ci][(co,ky,kx)] = sum_{(b,y,x)} a[b][ci][y][x] * gy[b][co][s*y+ky][s*x+kx]
+//       M = Cin, N = Cout*kh*kw, K = B*H*W, split over workgroups (fp64 atomics) and over the 4 waves.
+// BatchNorm+ReLU of the producer / BatchNorm-backward of the gradient are applied to the operands
+// as they are loaded; bias, BatchNorm sums and ReLU masking ride in the epilogues.
+#pragma once
+#include "kernels_gemm.h"
+
+namespace cae {
+
+
+// ---------------------------------------------------------------------------------------------
+struct IgFwd {
+    int B, Cin, H, W, Cout, OH, OW, KH, KW, QH, QW;
+    int tiles_per_wave;
+    const float* in;
+    BnDesc bn_in;
+    const float* w;
+    const float* bias;
+    float* out;
+    double* stats;  // [shards][Cout][4] or nullptr (eval)
+};
+
+// grid (ceil(Mtiles / (4*tiles_per_wave)), 4 parities, ceil(Cout/16)), block 256
+__global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
+    extern __shared__ double lds_d[];
+    float* lstat = reinterpret_cast<float*>(lds_d);  // [16 channels][2]
+    float4* cin4 = reinterpret_cast<float4*>(lstat + 32);
+    bn_consts(a.bn_in, cin4, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+    if (threadIdx.x < 32) lstat[threadIdx.x] = 0.f;
+    __syncthreads();
+
+    const int py = blockIdx.y >> 1, px = blockIdx.y & 1;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int j = q >> 1, i = q & 1;                 // this lane's tap inside the 2x2 neighbourhood
+    const int QQ = a.QH * a.QW;
+    const int M = a.B * QQ;
+    const int HW = a.H * a.W;
+    const int co = blockIdx.z * 16 + r;              // B column / C column of this lane
+    const int ky = py + 2 * j, kx = px + 2 * i;
+    const bool b_ok = co < a.Cout && ky < a.KH && kx < a.KW;
+    const float* bp = a.w + ((size_t)co * a.KH + ky) * a.KW + kx;
+    const size_t b_step = (size_t)a.Cout * a.KH * a.KW;
+    const float bias = co < a.Cout ? a.bias[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+
+    for (int tt = 0; tt < a.tiles_per_wave; tt++) {
+        const int tile = (blockIdx.x * 4 + wv) * a.tiles_per_wave + tt;
+        if (tile * 16 >= M) break;
+        // A row of this lane: quad m -> (b, qm, qn)
+        const int m = tile * 16 + r;
+        bool a_ok = m < M;
+        const int b = m / QQ, rem = m - b * QQ;
+        const int qm = rem / a.QW, qn = rem - qm * a.QW;
+        const int iy = qm - j, ix = qn - i;
+        a_ok = a_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const float* ap = a.in + (size_t)b * a.Cin * HW + (size_t)iy * a.W + ix;
+
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < a.Cin; c0 += 8) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int ci = c0 + u;
+                const bool c_ok = ci < a.Cin;
+                av[u] = (a_ok && c_ok) ? ap[(size_t)ci * HW] : 0.f;
+                bv[u] = (b_ok && c_ok) ? bp[(size_t)ci * b_step] : 0.f;
+                if (a.bn_in.mode != BN_NONE && a_ok && c_ok) {
+                    const float4 k = cin4[ci];
+                    av[u] = fmaxf(0.f, fmaf(av[u] - k.x, k.y, k.z));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        // epilogue: rows 4q..4q+3 of the tile, column co
+        if (co < a.Cout) {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int cm = tile * 16 + q * 4 + jj;
+                if (cm >= M) continue;
+                const int cb = cm / QQ, crem = cm - cb * QQ;
+                const int cqm = crem / a.QW, cqn = crem - cqm * a.QW;
+                const int oy = 2 * cqm + py, ox = 2 * cqn + px;
+                if (oy >= a.OH || ox >= a.OW) continue;
+                const float v = acc[jj] + bias;
+                a.out[((size_t)(cb * a.Cout + co) * a.OH + oy) * a.OW + ox] = v;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+            }
+        }
+    }
+    if (a.stats) {
+        // lanes r, r+16, r+32, r+48 hold the same channel: fold, then LDS, then one fp64 atomic per value
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (q == 0 && co < a.Cout) {
+            atomicAdd(&lstat[2 * r], s1);
+            atomicAdd(&lstat[2 * r + 1], s2);
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int c = blockIdx.z * 16 + (threadIdx.x >> 1);
+            if (c < a.Cout) {
+                const int shard = (blockIdx.x + blockIdx.y) & (kStatShards - 1);
+                atomicAdd(&a.stats[((size_t)shard * a.Cout + c) * 4 + (threadIdx.x & 1)], (double)lstat[threadIdx.x]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct IgDgrad {
+    int B, Cin, H, W, Cout, OH, OW, KH, KW, S;
+    int tiles_per_wave;
+    const float* g;        // (B,Cout,OH,OW) masked gradient (or dL/dy of the last layer)
+    const float* yout;     // raw forward output of this layer (BN_BWD) or nullptr
+    BnDesc bn_out;
+    const float* w;        // (Cin, Cout*KH*KW)
+    float* gin;            // (B,Cin,H,W)
+    const float* yprev;    // raw output of the producer (mask) or nullptr: plain store
+    BnDesc bn_prev;        // BN_SAVED of the producer or BN_NONE
+    double* stats_prev;    // [shards][Cin][4] slots 2,3
+};
+
+// grid (ceil(Mtiles / (4*tiles_per_wave)), ceil(Cin/16)), block 256; LDS: see host
+__global__ void __launch_bounds__(256) k_ig_dgrad(IgDgrad a) {
+    extern __shared__ double lds_d[];
+    const int K = a.Cout * a.KH * a.KW;
+    float* lstat = reinterpret_cast<float*>(lds_d);               // [16][2]
+    float4* cout4 = reinterpret_cast<float4*>(lstat + 32);        // [Cout]
+    float4* cprev4 = cout4 + a.Cout;                              // [Cin]
+    int* koff = reinterpret_cast<int*>(cprev4 + a.Cin);           // [K] offset of tap k inside one image of gy
+    bn_consts(a.bn_out, cout4, false);
+    bn_consts(a.bn_prev, cprev4, false);
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const int co = k / (a.KH * a.KW), t = k - co * (a.KH * a.KW);
+        const int ky = t / a.KW, kx = t - ky * a.KW;
+        koff[k] = (co * a.OH + ky) * a.OW + kx;
+    }
+    if (threadIdx.x < 32) lstat[threadIdx.x] = 0.f;
+    __syncthreads();
+
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int HW = a.H * a.W;
+    const int M = a.B * HW;
+    const int ci = blockIdx.y * 16 + r;
+    const bool b_ok = ci < a.Cin;
+    const float* bp = a.w + (size_t)ci * K;
+    const int khw = a.KH * a.KW;
+    float d1 = 0.f, d2 = 0.f;
+
+    for (int tt = 0; tt < a.tiles_per_wave; tt++) {
+        const int tile = (blockIdx.x * 4 + wv) * a.tiles_per_wave + tt;
+        if (tile * 16 >= M) break;
+        const int m = tile * 16 + r;
+        const bool a_ok = m < M;
+        const int b = m / HW, rem = m - b * HW;
+        const int y = rem / a.W, x = rem - y * a.W;
+        const size_t abase = (size_t)b * a.Cout * a.OH * a.OW + (size_t)(a.S * y) * a.OW + a.S * x;
+
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + 4 * u + q;
+                const bool k_ok = k < K;
+                float v = 0.f;
+                if (a_ok && k_ok) {
+                    const size_t off = abase + koff[k];
+                    v = a.g[off];
+                    if (a.bn_out.mode == BN_BWD) {
+                        const float4 c4 = cout4[k / khw];
+                        v = c4.y * v - c4.z - (a.yout[off] - c4.x) * c4.w;
+                    }
+                }
+                av[u] = v;
+                bv[u] = (b_ok && k_ok) ? bp[k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        if (b_ok) {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int cm = tile * 16 + q * 4 + jj;
+                if (cm >= M) continue;
+                const int cb = cm / HW, crem = cm - cb * HW;
+                const size_t off = ((size_t)cb * a.Cin + ci) * HW + crem;
+                float v = acc[jj];
+                if (a.bn_prev.mode != BN_NONE) {
+                    const float4 c4 = cprev4[ci];
+                    const float d = a.yprev[off] - c4.x;
+                    v = fmaf(d, c4.y, c4.z) > 0.f ? v : 0.f;
+                    d1 += v;
+                    d2 = fmaf(v, d * c4.w, d2);
+                }
+                a.gin[off] = v;
+            }
+        }
+    }
+    if (a.stats_prev) {
+        d1 += __shfl_xor(d1, 16, 64); d2 += __shfl_xor(d2, 16, 64);
+        d1 += __shfl_xor(d1, 32, 64); d2 += __shfl_xor(d2, 32, 64);
+        if (q == 0 && b_ok) {
+            atomicAdd(&lstat[2 * r], d1);
+            atomicAdd(&lstat[2 * r + 1], d2);
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int c = blockIdx.y * 16 + (threadIdx.x >> 1);
+            if (c < a.Cin) {
+                const int shard = blockIdx.x & (kStatShards - 1);
+                atomicAdd(&a.stats_prev[((size_t)shard * a.Cin + c) * 4 + 2 + (threadIdx.x & 1)], (double)lstat[threadIdx.x]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct IgWgrad {
+    int B, Cin, H, W, Cout, OH, OW, KH, KW, S;
+    int ksteps_per_block;  // MFMA k-steps (of 4 positions) per workgroup
+    const float* ain;      // (B,Cin,H,W) raw output of the producer (or plain activations)
+    BnDesc bn_in;          // BN_SAVED or BN_NONE
+    const float* g;
+    const float* yout;
+    BnDesc bn_out;         // BN_BWD or BN_NONE
+    double* wacc;          // (Cin, Cout*KH*KW) fp64 accumulator
+    BnGradOut bg;
+};
+
+// grid (Mtiles*Ntiles, K chunks), block 256: the 4 waves split the chunk, LDS combine, fp64 atomics
+__global__ void __launch_bounds__(256) k_ig_wgrad(IgWgrad a) {
+    extern __shared__ double lds_d[];
+    float* part = reinterpret_cast<float*>(lds_d);            // [4][256]
+    float4* cin4 = reinterpret_cast<float4*>(part + 1024);    // [Cin]
+    float4* cout4 = cin4 + a.Cin;                             // [Cout]
+    bn_consts(a.bn_in, cin4, false);
+    bn_consts(a.bn_out, cout4, false);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && a.bg.stats) {
+        for (int c = threadIdx.x; c < a.bg.C; c += 256) {
+            double sb = 0.0, sg = 0.0;
+            for (int sh = 0; sh < kStatShards; sh++) {
+                sb += a.bg.stats[((size_t)sh * a.bg.C + c) * 4 + 2];
+                sg += a.bg.stats[((size_t)sh * a.bg.C + c) * 4 + 3];
+            }
+            a.bg.beta_acc[c] = sb * a.bg.scale;
+            a.bg.gamma_acc[c] = sg * a.bg.scale;
+        }
+    }
+    __syncthreads();
+
+    const int khw = a.KH * a.KW;
+    const int N = a.Cout * khw;
+    const int HW = a.H * a.W;
+    const int K = a.B * HW;
+    const int tiles_n = (N + 15) >> 4;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int ci = tm * 16 + r;                      // A row of this lane
+    const int n = tn * 16 + r;                       // B column of this lane: (co, ky, kx)
+    const bool a_ok = ci < a.Cin, b_ok = n < N;
+    const int co = b_ok ? n / khw : 0;
+    const int t = n - co * khw;
+    const int ky = t / a.KW, kx = t - ky * a.KW;
+    const size_t nbase = ((size_t)co * a.OH + ky) * a.OW + kx;
+    const float4 ka = (a.bn_in.mode != BN_NONE && a_ok) ? cin4[ci] : make_float4(0, 0, 0, 0);
+    const float4 kb = (a.bn_out.mode == BN_BWD && b_ok) ? cout4[co] : make_float4(0, 0, 0, 0);
+
+    const int steps = (K + 3) >> 2;
+    const int s_begin = blockIdx.y * a.ksteps_per_block;
+    const int s_end = min(steps, s_begin + a.ksteps_per_block);
+    const int per = (s_end - s_begin + 3) >> 2;
+    const int s0 = s_begin + wv * per, s1 = min(s_end, s0 + per);
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int st = s0; st < s1; st += 8) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = (st + u) * 4 + q;
+            const bool k_ok = (st + u) < s1 && k < K;
+            const int b = k / HW, pos = k - b * HW;
+            const int y = pos / a.W, x = pos - y * a.W;
+            float va = 0.f, vb = 0.f;
+            if (a_ok && k_ok) {
+                va = a.ain[((size_t)b * a.Cin + ci) * HW + pos];
+                if (a.bn_in.mode != BN_NONE) va = fmaxf(0.f, fmaf(va - ka.x, ka.y, ka.z));
+            }
+            if (b_ok && k_ok) {
+                const size_t off = (size_t)b * a.Cout * a.OH * a.OW + (size_t)(a.S * y) * a.OW + a.S * x + nbase;
+                vb = a.g[off];
+                if (a.bn_out.mode == BN_BWD) vb = kb.y * vb - kb.z - (a.yout[off] - kb.x) * kb.w;
+            }
+            av[u] = va;
+            bv[u] = vb;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) part[wv * 256 + j * 64 + lane] = acc[j];
+    __syncthreads();
+    if (wv != 0) return;
+    const int cn = tn * 16 + r;
+    if (cn >= N) return;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int cm = tm * 16 + q * 4 + j;
+        if (cm >= a.Cin) continue;
+        const float v = part[j * 64 + lane] + part[256 + j * 64 + lane] + part[512 + j * 64 + lane] + part[768 + j * 64 + lane];
+        atomicAdd(&a.wacc[(size_t)cm * N + cn], (double)v);
+    }
+}
+
+}  // namespace cae

@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) k_s2_fwd(S2Fwd a) {
             const double s = red[i] + red[2 * COUT + i] + red[4 * COUT + i] + red[6 * COUT + i];
             const int co = i >> 1;
             if (EPI == S2_RAW_STATS) {
-                atomicAdd(&a.stats[4 * co + (i & 1)], s);
+                atomicAdd(&a.stats[((size_t)(blockIdx.x & (kStatShards - 1)) * COUT + co) * 4 + (i & 1)], s);
             } else {
                 if ((i & 1) == 0) {
                     atomicAdd(&a.losses[a.st->loss_slot], s);
@@ -272,8 +272,13 @@ __global__ void __launch_bounds__(256) k_s2_bwd(S2Bwd a) {
     bn_consts(a.bn_in, cin4, false);
     if (blockIdx.x == 0 && a.bg.stats) {
         for (int c = threadIdx.x; c < a.bg.C; c += 256) {
-            a.bg.beta_acc[c] = a.bg.stats[4 * c + 2] * a.bg.scale;
-            a.bg.gamma_acc[c] = a.bg.stats[4 * c + 3] * a.bg.scale;
+            double sb = 0.0, sg = 0.0;
+            for (int sh = 0; sh < kStatShards; sh++) {
+                sb += a.bg.stats[((size_t)sh * a.bg.C + c) * 4 + 2];
+                sg += a.bg.stats[((size_t)sh * a.bg.C + c) * 4 + 3];
+            }
+            a.bg.beta_acc[c] = sb * a.bg.scale;
+            a.bg.gamma_acc[c] = sg * a.bg.scale;
         }
     }
 
@@ -400,7 +405,7 @@ __global__ void __launch_bounds__(256) k_s2_bwd(S2Bwd a) {
         } else if (a.stats_in) {
             const int jj = j - NACC;
             const int ci = gsel * CT + (jj >> 1);
-            atomicAdd(&a.stats_in[4 * ci + 2 + (jj & 1)], s);
+            atomicAdd(&a.stats_in[((size_t)(blockIdx.x & (kStatShards - 1)) * CIN + ci) * 4 + 2 + (jj & 1)], s);
         }
     }
 }
