@@ -54,6 +54,7 @@ struct ConvLayer {
     int64_t w_off, b_off, gamma_off, beta_off;  // parameter arena (floats)
     int64_t rm_off, rv_off;                     // buffer arena (floats)
     int64_t act_off, grad_off;                  // workspace (bytes): raw output y / masked gradient g
+    int sh_w = -1, sh_b = -1;                   // offsets in the sharded gradient table (-1: not sharded)
     int64_t out_elems() const { return (int64_t)cout * hout * wout; }
     int64_t in_elems() const { return (int64_t)cin * hin * win; }
 };
@@ -82,7 +83,8 @@ struct cae_engine {
 
     // workspace carve (byte offsets)
     int64_t off_state = 0, off_losses = 0, off_zero_begin = 0, off_gradacc = 0, off_zero_end = 0;
-    int64_t off_glast = 0, off_scan = 0;
+    int64_t off_glast = 0, off_scan = 0, off_sgacc = 0;
+    ShardSegs segs{};                      // sharded gradient accumulators (thin stride-2 layers)
     int64_t ws_need = 0;
 
     // bound memory
@@ -105,6 +107,12 @@ struct cae_engine {
     StepState* state() const { return reinterpret_cast<StepState*>(ws + off_state); }
     double* losses() const { return reinterpret_cast<double*>(ws + off_losses); }
     double* gradacc() const { return reinterpret_cast<double*>(ws + off_gradacc); }
+    double* sgacc() const { return reinterpret_cast<double*>(ws + off_sgacc); }
+    ShardSegs shard_segs() const {
+        ShardSegs r = segs;
+        r.base = sgacc();
+        return r;
+    }
     double* bn_stats(int j) const { return reinterpret_cast<double*>(ws + bn_stat_off[j]); }
     float* bn_saved(int j) const { return reinterpret_cast<float*>(ws + bn_saved_off[j]); }
     float* fptr(int64_t off) const { return reinterpret_cast<float*>(ws + off); }
@@ -246,14 +254,15 @@ struct StepArgs {
 #define S2_SHAPES(X) X(2, 1) X(4, 2) X(8, 4) X(6, 3)
 #define S2_KERNELS(X, CI, CO) X(CI, CO, 3, 3) X(CI, CO, 4, 4) X(CI, CO, 3, 4) X(CI, CO, 4, 3)
 
-bool s2_eligible(const cae_engine* e, const ConvLayer& L) {
-    if (!e->use_s2 || !L.transposed || L.stride != 2) return false;
+bool s2_shape_ok(const ConvLayer& L) {
+    if (!L.transposed || L.stride != 2) return false;
     if (L.kh < 3 || L.kh > 4 || L.kw < 3 || L.kw > 4) return false;
 #define CHK(CI, CO) if (L.cin == CI && L.cout == CO) return true;
     S2_SHAPES(CHK)
 #undef CHK
     return false;
 }
+bool s2_eligible(const cae_engine* e, const ConvLayer& L) { return e->use_s2 && L.sh_w >= 0 && s2_shape_ok(L); }
 
 template <int CIN, int COUT, int KH, int KW>
 void s2_fwd_launch(S2Fwd a, hipStream_t s) {
@@ -261,11 +270,13 @@ void s2_fwd_launch(S2Fwd a, hipStream_t s) {
     if (qx > 32) {
         a.tiles_x = (qx + 63) / 64;
         a.tiles_y = (qy + 3) / 4;
-        hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 64>), dim3(a.B * a.tiles_x * a.tiles_y), dim3(256), 0, s, a);
+        a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+        hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
     } else {
         a.tiles_x = (qx + 31) / 32;
         a.tiles_y = (qy + 7) / 8;
-        hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 32>), dim3(a.B * a.tiles_x * a.tiles_y), dim3(256), 0, s, a);
+        a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+        hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
     }
 }
 
@@ -287,7 +298,7 @@ void s2_bwd_launch(S2Bwd a, hipStream_t s) {
     a.tiles_x = (a.W + TPX - 1) / TPX;
     a.tiles_y = (a.H + TPY - 1) / TPY;
     a.total_tiles = a.B * a.tiles_x * a.tiles_y;
-    const int grid = a.total_tiles < 768 ? a.total_tiles : 768;
+    const int grid = a.total_tiles < 1024 ? a.total_tiles : 1024;
     hipLaunchKernelGGL((k_s2_bwd<CIN, CT, COUT, KH, KW, TPX, TPY>), dim3(grid), dim3(256), 0, s, a);
 }
 
@@ -423,7 +434,8 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
                 f.use_cursor = ep.use_cursor;
                 f.losses = ep.losses;
                 f.inv_count = ep.inv_count;
-                f.bias_acc = ep.bias_acc;
+                f.bias_acc = e->sgacc() + L.sh_b;
+                f.bias_stride = e->segs.n;
                 f.epi = a.train ? S2_SIGMSE : S2_SIGOUT;
             }
             ProfScope _p(e, last ? (a.train ? "s2_convt_last_fwd_loss" : "s2_convt_last_eval") : (a.train ? "s2_convt_fwd" : "s2_convt_eval"), (int)l,
@@ -495,7 +507,8 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             f.ain = ain.p;
             f.bn_in = bna;
             f.w = e->params + L.w_off;
-            f.wacc = acc + L.w_off;
+            f.wacc = e->sgacc() + L.sh_w;
+            f.wacc_stride = e->segs.n;
             if (l == 0) {
                 f.gin = e->fptr(e->fc[3].grad_off);
             } else {
@@ -752,11 +765,11 @@ int launch_op(cae_engine* e, int op, const StepArgs& a) {
             ProfScope _p(e, "adam", 0, 32.0 * e->n_param);
             hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
                                (const double*)e->gradacc(), (const float*)nullptr, e->m, e->v, e->hp,
-                               (const StepState*)e->state());
+                               (const StepState*)e->state(), e->shard_segs());
             hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), a.batch, 1, 1);
         } else {
             hipLaunchKernelGGL(k_acc_to_f32, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param,
-                               (const double*)e->gradacc(), e->grads);
+                               (const double*)e->gradacc(), e->grads, e->shard_segs());
             hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), a.batch, 1, 0);
         }
     } else if (op == OP_EVAL) {
@@ -766,7 +779,7 @@ int launch_op(cae_engine* e, int op, const StepArgs& a) {
     } else if (op == OP_ADAM) {
         hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
                            (const double*)nullptr, (const float*)e->grads, e->m, e->v, e->hp,
-                           (const StepState*)e->state());
+                           (const StepState*)e->state(), e->shard_segs());
         hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), 0, 0, 1);
     }
     HIP_TRY(hipGetLastError());
@@ -919,10 +932,29 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
     e->n_buf = align_up(e->n_buf, 4);
     e->n_bn = bn;
 
+    // ---- sharded accumulators for the layers the stride-2 kernels can take
+    {
+        int n = 0;
+        for (size_t l = 0; l < e->dec.size(); l++) {
+            ConvLayer& L = e->dec[l];
+            if (!s2_shape_ok(L) || e->segs.nseg + 2 > 12) continue;
+            const int nw = L.cin * L.cout * L.kh * L.kw;
+            L.sh_w = n;
+            e->segs.seg[e->segs.nseg++] = ShardSeg{L.w_off, nw, n};
+            n += (nw + 3) / 4 * 4;
+            if (l + 1 == e->dec.size()) {
+                L.sh_b = n;
+                e->segs.seg[e->segs.nseg++] = ShardSeg{L.b_off, L.cout, n};
+                n += (L.cout + 3) / 4 * 4;
+            }
+        }
+        e->segs.n = n;
+    }
+
     // ---- workspace carve
     int64_t top = 0;
     e->off_state = carve(top, sizeof(StepState));
-    e->off_losses = carve(top, (int64_t)kLossSlots * sizeof(double));
+    e->off_losses = carve(top, (int64_t)kLossSlots * kStatShards * sizeof(double));
     e->off_scan = carve(top, 1024 * 3 * sizeof(double));
     e->bn_stat_off.resize(bn);
     e->bn_saved_off.resize(bn);
@@ -937,6 +969,7 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
     for (auto& L : e->enc) reg_bn(L);
     for (auto& L : e->dec) reg_bn(L);
     e->off_gradacc = carve(top, e->n_param * (int64_t)sizeof(double));
+    e->off_sgacc = carve(top, (int64_t)kStatShards * (e->segs.n > 0 ? e->segs.n : 4) * (int64_t)sizeof(double));
     e->off_zero_end = align_up(top, 256);
     top = e->off_zero_end;
     for (auto& L : e->enc) e->bn_saved_off[L.bn_index] = carve(top, (int64_t)L.cout * 2 * sizeof(float));
@@ -1097,9 +1130,16 @@ int cae_read_losses(cae_engine* e, int first, int count, double* host_out) {
     if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
     if (first < 0 || count < 0 || first + count > kLossSlots || !host_out) return fail(CAE_ERR_ARG, "bad loss range");
     if (count == 0) return CAE_OK;
-    HIP_TRY(hipMemcpyAsync(host_out, e->losses() + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemsetAsync(e->losses() + first, 0, (size_t)count * sizeof(double), e->stream));
+    std::vector<double> raw((size_t)count * kStatShards);
+    double* dev = e->losses() + (size_t)first * kStatShards;
+    HIP_TRY(hipMemcpyAsync(raw.data(), dev, raw.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemsetAsync(dev, 0, raw.size() * sizeof(double), e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < count; i++) {
+        double t = 0.0;
+        for (int sh = 0; sh < kStatShards; sh++) t += raw[(size_t)i * kStatShards + sh];
+        host_out[i] = t;
+    }
     return CAE_OK;
 }
 

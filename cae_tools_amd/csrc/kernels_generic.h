@@ -23,6 +23,31 @@ namespace cae {
 // consumers add the copies up in bn_consts.
 constexpr int kStatShards = 8;
 
+// Gradient accumulators that many workgroups hit at once (weights of the thin stride-2 layers,
+// the last layer's bias) live in a sharded side table [kStatShards][n]; Adam adds the shards up.
+struct ShardSeg {
+    long long param_off;  // first parameter of the segment in the flat arena
+    int count;
+    int sh_off;           // offset inside one shard
+};
+struct ShardSegs {
+    int nseg;
+    int n;                // doubles per shard
+    const double* base;   // [kStatShards][n]
+    ShardSeg seg[12];
+};
+
+__device__ __forceinline__ double sharded_grad(const ShardSegs& ss, long long i) {
+    double g = 0.0;
+    for (int s = 0; s < ss.nseg; s++) {
+        const long long d = i - ss.seg[s].param_off;
+        if (d >= 0 && d < ss.seg[s].count) {
+            for (int sh = 0; sh < kStatShards; sh++) g += ss.base[(size_t)sh * ss.n + ss.seg[s].sh_off + d];
+        }
+    }
+    return g;
+}
+
 struct StepState {
     long long batch_start;  // first position in the permutation of the current batch
     int loss_slot;          // where this step's loss is accumulated
@@ -227,10 +252,10 @@ __device__ __forceinline__ void epi_block(const Epi& e, int c, const StepState* 
             atomicAdd(&e.stats[row + 2], t1);
             atomicAdd(&e.stats[row + 3], t2);
         } else if (e.kind == EPI_SIGMSE) {
-            atomicAdd(&e.losses[st->loss_slot], t1);
+            atomicAdd(&e.losses[(size_t)st->loss_slot * kStatShards + (blockIdx.x & (kStatShards - 1))], t1);
             atomicAdd(&e.bias_acc[c], t2);
         } else {
-            atomicAdd(&e.losses[st->loss_slot], t1);
+            atomicAdd(&e.losses[(size_t)st->loss_slot * kStatShards + (blockIdx.x & (kStatShards - 1))], t1);
         }
     }
 }
@@ -514,7 +539,8 @@ struct Hyper {
 // over the flat arena.  Gradient source: fp64 accumulator (fused path) or fp32 arena (DP path).
 __global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p, const double* __restrict__ acc,
                                                const float* __restrict__ g32, float* __restrict__ m,
-                                               float* __restrict__ v, Hyper h, const StepState* __restrict__ st) {
+                                               float* __restrict__ v, Hyper h, const StepState* __restrict__ st,
+                                               ShardSegs ss) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int t = st->adam_step + 1;
@@ -523,7 +549,7 @@ __global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p
     const float step_size = (float)(h.lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     const float b1 = (float)h.beta1, b2 = (float)h.beta2;
-    float g = acc ? (float)acc[i] : g32[i];
+    float g = acc ? (float)(acc[i] + sharded_grad(ss, i)) : g32[i];
     const float w = p[i];
     if (h.wd != 0.0) g = fmaf((float)h.wd, w, g);
     float mi = m[i], vi = v[i];
@@ -535,9 +561,9 @@ __global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p
     v[i] = vi;
 }
 
-__global__ void k_acc_to_f32(long long n, const double* __restrict__ acc, float* __restrict__ g) {
+__global__ void k_acc_to_f32(long long n, const double* __restrict__ acc, float* __restrict__ g, ShardSegs ss) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) g[i] = (float)acc[i];
+    if (i < n) g[i] = (float)(acc[i] + sharded_grad(ss, i));
 }
 
 __global__ void k_set_state(StepState* st, long long batch_start, int loss_slot, int set_cursor, int adam_step,

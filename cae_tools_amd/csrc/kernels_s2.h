@@ -26,6 +26,7 @@ namespace cae {
 struct S2Fwd {
     int B, H, W, OH, OW;     // input map H x W, output map OH x OW (per channel)
     int tiles_x, tiles_y;    // quad tiles per image
+    int total_tiles;
     const float* in;         // (B, CIN, H, W) raw output of the producer (or plain activations)
     const float* w;          // (CIN, COUT, KH, KW)
     const float* bias;       // (COUT)
@@ -38,7 +39,8 @@ struct S2Fwd {
     int use_cursor;
     double* losses;
     float inv_count;
-    double* bias_acc;
+    double* bias_acc;        // sharded: [kStatShards][bias_stride], this layer's bias at bias_acc[shard*stride + co]
+    int bias_stride;
     const StepState* st;
     int epi;                 // S2_RAW_STATS | S2_RAW | S2_SIGMSE | S2_SIGOUT
 };
@@ -83,8 +85,13 @@ __global__ void __launch_bounds__(256) k_s2_fwd(S2Fwd a) {
     __syncthreads();
 
     const int tiles = a.tiles_x * a.tiles_y;
-    const int b = blockIdx.x / tiles;
-    const int t = blockIdx.x - b * tiles;
+    double r[2 * COUT];
+#pragma unroll
+    for (int i = 0; i < 2 * COUT; i++) r[i] = 0.0;
+
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    const int b = tile / tiles;
+    const int t = tile - b * tiles;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int n = tx * TW + (threadIdx.x % TW);
     const int m = ty * TH + (threadIdx.x / TW);
@@ -143,10 +150,6 @@ __global__ void __launch_bounds__(256) k_s2_fwd(S2Fwd a) {
     const int oy = 2 * m, ox = 2 * n;
     const bool row1 = active && (oy + 1 < a.OH);
     const bool col1 = active && (ox + 1 < a.OW);
-    double r[2 * COUT];
-#pragma unroll
-    for (int i = 0; i < 2 * COUT; i++) r[i] = 0.0;
-
     if (EPI == S2_RAW_STATS || EPI == S2_RAW) {
         if (active) {
 #pragma unroll
@@ -161,8 +164,8 @@ __global__ void __launch_bounds__(256) k_s2_fwd(S2Fwd a) {
                         s1 += acc[co][1][0]; s2 = fmaf(acc[co][1][0], acc[co][1][0], s2);
                         if (col1) { s1 += acc[co][1][1]; s2 = fmaf(acc[co][1][1], acc[co][1][1], s2); }
                     }
-                    r[2 * co] = (double)s1;
-                    r[2 * co + 1] = (double)s2;
+                    r[2 * co] += (double)s1;
+                    r[2 * co + 1] += (double)s2;
                 }
             }
         }
@@ -196,11 +199,13 @@ __global__ void __launch_bounds__(256) k_s2_fwd(S2Fwd a) {
                     }
                     if (o) store_pair(o + py * a.OW, res[0], res[1], col1);
                 }
-                r[2 * co] = (double)lsum * (double)a.inv_count;
-                r[2 * co + 1] = (double)gsum;
+                r[2 * co] += (double)lsum * (double)a.inv_count;
+                r[2 * co + 1] += (double)gsum;
             }
         }
     }
+
+    }  // tile loop
 
     if (EPI != S2_RAW) {
         if (EPI == S2_SIGOUT && !a.target) return;
@@ -219,10 +224,11 @@ __global__ void __launch_bounds__(256) k_s2_fwd(S2Fwd a) {
             if (EPI == S2_RAW_STATS) {
                 atomicAdd(&a.stats[((size_t)(blockIdx.x & (kStatShards - 1)) * COUT + co) * 4 + (i & 1)], s);
             } else {
+                const int shard = blockIdx.x & (kStatShards - 1);
                 if ((i & 1) == 0) {
-                    atomicAdd(&a.losses[a.st->loss_slot], s);
+                    atomicAdd(&a.losses[(size_t)a.st->loss_slot * kStatShards + shard], s);
                 } else if (EPI == S2_SIGMSE) {
-                    atomicAdd(&a.bias_acc[co], s);
+                    atomicAdd(&a.bias_acc[(size_t)shard * a.bias_stride + co], s);
                 }
             }
         }
@@ -243,7 +249,8 @@ struct S2Bwd {
     const float* w;          // (CIN, COUT, KH, KW)
     float* gin;              // (B, CIN, H, W) gradient wrt the producer's raw output side: masked by its ReLU
     double* stats_in;        // producer's [CIN][4] sums (slots 2,3), or nullptr when bn_in is BN_NONE
-    double* wacc;            // fp64 accumulator of dW
+    double* wacc;            // sharded fp64 accumulator of dW: [kStatShards][wacc_stride]
+    int wacc_stride;
     BnGradOut bg;            // BatchNorm parameter gradients of this layer (published by block 0)
 };
 
@@ -401,7 +408,7 @@ __global__ void __launch_bounds__(256) k_s2_bwd(S2Bwd a) {
             // j = ((c*COUT + co)*KH + ky)*KW + kx  ->  global weight index with ci = gsel*CT + c
             const int c = j / (COUT * KH * KW), rest = j - c * (COUT * KH * KW);
             const int ci = gsel * CT + c;
-            atomicAdd(&a.wacc[(size_t)ci * COUT * KH * KW + rest], s);
+            atomicAdd(&a.wacc[(size_t)(blockIdx.x & (kStatShards - 1)) * a.wacc_stride + (size_t)ci * COUT * KH * KW + rest], s);
         } else if (a.stats_in) {
             const int jj = j - NACC;
             const int ci = gsel * CT + (jj >> 1);
