@@ -1,0 +1,224 @@
+"""Minimal named-array containers and NetCDF-3 I/O for the ConvAE drop-in.
+
+The reference passes xarray Datasets around (cli/train_cae.py:58-59, base_model.py:151-152) and
+touches only a small duck-typed surface of them: ds[name] -> .shape/.dims/.values/.data, item
+assignment, ds.dims, to_netcdf, open_mfdataset(concat_dim=..., combine="nested").  xarray is not
+a dependency of this package (and is absent from the build image): Dataset/DataArray below
+provide exactly that surface over numpy arrays, and every model entry point accepts either these
+or real xarray objects.  Files are NetCDF-3 classic / 64-bit-offset through scipy.io.netcdf_file;
+NetCDF-4 (HDF5) files need xarray + netCDF4/h5netcdf, which open_dataset uses when importable.
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+
+class DataArray:
+
+    def __init__(self, data, dims=None, attrs=None, coords=None):
+        self._data = np.asarray(data)
+        if dims is None:
+            dims = tuple(f"dim_{i}" for i in range(self._data.ndim))
+        if len(dims) != self._data.ndim:
+            raise ValueError(f"{len(dims)} dimension names for a {self._data.ndim}-d array")
+        self.dims = tuple(dims)
+        self.attrs = dict(attrs or {})
+
+    # the attributes the model code reads
+    @property
+    def shape(self):
+        return self._data.shape
+
+    @property
+    def values(self):
+        return self._data
+
+    @property
+    def data(self):
+        return self._data
+
+    @property
+    def dtype(self):
+        return self._data.dtype
+
+    @property
+    def size(self):
+        return self._data.size
+
+    @property
+    def ndim(self):
+        return self._data.ndim
+
+    def __getitem__(self, key):
+        sub = self._data[key]
+        if not isinstance(key, tuple):
+            key = (key,)
+        dims = [d for d, k in zip(self.dims, list(key) + [slice(None)] * (self.ndim - len(key)))
+                if not isinstance(k, (int, np.integer))]
+        return DataArray(sub, dims=dims if len(dims) == np.ndim(sub) else None, attrs=self.attrs)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        return self._data if dtype is None else self._data.astype(dtype)
+
+    def __repr__(self):
+        return f"<DataArray {dict(zip(self.dims, self.shape))} {self.dtype}>"
+
+
+class _Dims(dict):
+    """ds.dims['y'] -> length (cli/train_cae.py:77-78)"""
+
+
+class Dataset:
+
+    def __init__(self, data_vars=None, attrs=None):
+        self._vars = OrderedDict()
+        self.attrs = dict(attrs or {})
+        for k, v in (data_vars or {}).items():
+            self[k] = v
+
+    def __getitem__(self, name):
+        if name in self._vars:
+            return self._vars[name]
+        if name in self.dims:  # a bare dimension: index coordinate, like xarray
+            return DataArray(np.arange(self.dims[name]), dims=(name,))
+        raise KeyError(name)
+
+    def __setitem__(self, name, value):
+        if not isinstance(value, DataArray):
+            if hasattr(value, "dims") and hasattr(value, "values"):
+                value = DataArray(np.asarray(value.values), dims=tuple(value.dims), attrs=getattr(value, "attrs", {}))
+            else:
+                raise TypeError("assign a DataArray (data + dims)")
+        for d, n in zip(value.dims, value.shape):
+            known = self.dims.get(d)
+            if known is not None and known != n:
+                raise ValueError(f"dimension '{d}' has length {known}, variable '{name}' wants {n}")
+        self._vars[name] = value
+
+    def __contains__(self, name):
+        return name in self._vars
+
+    def __iter__(self):
+        return iter(self._vars)
+
+    def keys(self):
+        return self._vars.keys()
+
+    @property
+    def data_vars(self):
+        return self._vars
+
+    @property
+    def dims(self):
+        out = _Dims()
+        for v in self._vars.values():
+            for d, n in zip(v.dims, v.shape):
+                out.setdefault(d, n)
+        return out
+
+    def to_netcdf(self, path):
+        write_netcdf3(self, path)
+
+    def __repr__(self):
+        rows = [f"  {k}: {v!r}" for k, v in self._vars.items()]
+        return "<Dataset\n" + "\n".join(rows) + "\n>"
+
+
+# ---------------------------------------------------------------------------------------------
+# NetCDF-3
+# ---------------------------------------------------------------------------------------------
+
+def write_netcdf3(ds, path):
+    from scipy.io import netcdf_file
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with netcdf_file(path, "w", version=2) as f:
+        for d, n in ds.dims.items():
+            f.createDimension(d, int(n))
+        for name, da in ds.data_vars.items():
+            arr = np.asarray(da.values)
+            if arr.dtype == np.float16:
+                arr = arr.astype(np.float32)
+            if arr.dtype == np.int64:  # NetCDF-3 has no 64-bit integers
+                arr = arr.astype(np.int32)
+            if arr.dtype == bool:
+                arr = arr.astype(np.int8)
+            var = f.createVariable(name, arr.dtype.newbyteorder("=").char if arr.dtype.kind != "S" else "c", da.dims)
+            var[...] = arr
+            for k, v in da.attrs.items():
+                try:
+                    setattr(var, k, v)
+                except Exception:
+                    pass
+        for k, v in ds.attrs.items():
+            try:
+                setattr(f, k, v)
+            except Exception:
+                pass
+
+
+def _is_hdf5(path):
+    with open(path, "rb") as f:
+        return f.read(4) == b"\x89HDF"
+
+
+def open_dataset(path):
+    """One NetCDF file -> Dataset (arrays are copied out of the file mapping)."""
+    if _is_hdf5(path):
+        try:
+            import xarray as xr
+        except ImportError as ex:
+            raise RuntimeError(f"{path} is NetCDF-4/HDF5; reading it needs xarray with netCDF4 or h5netcdf "
+                               "(not available) - convert it to NetCDF-3 (ncks -3 / nccopy -k classic)") from ex
+        return from_xarray(xr.open_dataset(path))
+    from scipy.io import netcdf_file
+    out = Dataset()
+    with netcdf_file(path, "r", mmap=False) as f:
+        for name, var in f.variables.items():
+            arr = np.array(var[...])
+            if arr.dtype.byteorder == ">":
+                arr = arr.astype(arr.dtype.newbyteorder("="))
+            attrs = {k: getattr(var, k) for k in getattr(var, "_attributes", {})}
+            out[name] = DataArray(arr, dims=tuple(var.dimensions), attrs=attrs)
+    return out
+
+
+def from_xarray(xds):
+    out = Dataset(attrs=dict(xds.attrs))
+    for name in xds.data_vars:
+        v = xds[name]
+        out[name] = DataArray(np.asarray(v.values), dims=tuple(v.dims), attrs=dict(v.attrs))
+    return out
+
+
+def open_mfdataset(paths, concat_dim="box", combine="nested", **_ignored):
+    """Nested concatenation of several files along a NEW or existing dimension, the way the CLIs
+    call xr.open_mfdataset(paths, concat_dim="box", combine="nested") (cli/train_cae.py:58-59):
+    variables that carry `concat_dim` are concatenated along it; if no variable has that dimension
+    (the reference's test data uses "n"), every variable gains it as a new leading axis - for a
+    single file xarray then leaves the data unchanged, which is what this does too."""
+    if isinstance(paths, (str, os.PathLike)):
+        paths = [paths]
+    parts = [open_dataset(p) for p in paths]
+    if len(parts) == 1:
+        return parts[0]
+    out = Dataset(attrs=parts[0].attrs)
+    for name in parts[0].data_vars:
+        das = [p[name] for p in parts]
+        dims = das[0].dims
+        if concat_dim in dims:
+            axis = dims.index(concat_dim)
+            out[name] = DataArray(np.concatenate([d.values for d in das], axis=axis), dims=dims, attrs=das[0].attrs)
+        else:
+            out[name] = DataArray(np.stack([d.values for d in das], axis=0), dims=(concat_dim,) + dims,
+                                  attrs=das[0].attrs)
+    return out
+
+
+def as_numpy(var):
+    """values of a DataArray-like (ours, xarray's, dask-backed) as a numpy array"""
+    v = var.values if hasattr(var, "values") else var
+    return np.asarray(v)

@@ -1,0 +1,123 @@
+"""BaseModel — shared model plumbing with the reference's public surface
+(src/cae_tools/models/base_model.py): model id (:33,56-61), io-spec accessors (:35-54),
+evaluate (:69-100), apply (:102-152), dump_metrics (:154-157), save/load of input_spec.json /
+output_spec.json (:162-180).  Scoring and denormalisation run on the GPU through the engine;
+metrics stay on the host as in the reference."""
+import json
+import os
+import uuid
+
+import numpy as np
+import torch
+
+from ..data.arrays import DataArray
+from .ds_dataset import DSDataset
+from .model_metric import ModelMetric
+
+
+def _make_data_array(like_ds, data, dims):
+    """DataArray of the same family as the dataset it is assigned into"""
+    if type(like_ds).__module__.startswith("xarray"):
+        import xarray as xr
+        return xr.DataArray(data, dims=dims)
+    return DataArray(data, dims=dims)
+
+
+class BaseModel:
+
+    def __init__(self):
+        self.input_spec = None
+        self.output_spec = None
+        self.model_id = str(uuid.uuid4())
+
+    def set_input_spec(self, input_spec):
+        self.input_spec = input_spec
+
+    def get_input_spec(self):
+        return self.input_spec
+
+    def set_output_spec(self, output_spec):
+        self.output_spec = output_spec
+
+    def get_output_spec(self):
+        return self.output_spec
+
+    def get_input_variable_names(self):
+        return None if self.input_spec is None else [item["name"] for item in self.input_spec]
+
+    def get_output_variable_name(self):
+        return None if self.output_spec is None else self.output_spec["name"]
+
+    def set_model_id(self, model_id):
+        self.model_id = model_id
+
+    def get_model_id(self):
+        return self.model_id
+
+    def torch_load(self, from_path):
+        return torch.load(from_path, map_location=torch.device("cpu"), weights_only=True)
+
+    # ---- scoring helpers -------------------------------------------------------------------
+    def _score_device(self, x):
+        """eval-mode forward of an (N,C,H,W) fp32 CUDA tensor; implemented by the sub-class"""
+        raise NotImplementedError
+
+    def evaluate(self, dataset, device=None):
+        """score every case, denormalise, and pool the reference's metrics (:69-100).  The mask is
+        all ones for ConvAEModel (the reference builds it with the INPUT's shape, which cannot index
+        the output; the intended all-pixels mask is used here - SURVEY.md headline fact 3)."""
+        dataset.set_normalise_output(False)
+        x = dataset.device_inputs()
+        truth = dataset.device_outputs().cpu().numpy()
+        scores = dataset.denormalise_device(self._score_device(x)).cpu().numpy()
+        mm = ModelMetric()
+        ones = np.ones(truth.shape[1:], dtype=np.float32)
+        for i in range(truth.shape[0]):
+            mm.accumulate(truth[i], scores[i], ones)
+        return mm.get_metrics()
+
+    def apply(self, score_ds, input_variables, prediction_variable="model_output",
+              channel_dimension="model_output_channel", y_dimension="model_output_y",
+              x_dimension="model_output_x", mask_variable_name=None):
+        """Add `prediction_variable` (float64, denormalised, dims (case, channel, y, x)) to score_ds
+        in place (:102-152)."""
+        first = score_ds[input_variables[0]]
+        n_dimension = first.dims[0]
+        ds = DSDataset(score_ds, input_variables, input_variables[0], normalise_in=self.normalise_input,
+                       mask_variable_name=mask_variable_name)
+        ds.set_normalisation_parameters(self.normalisation_parameters)
+        y = self._score_device(ds.device_inputs())
+        out = ds.denormalise_device(y)   # fp64 on the device: min + y*(max-min), then one D2H copy
+        score_ds[prediction_variable] = _make_data_array(score_ds, out.cpu().numpy(),
+                                                         (n_dimension, channel_dimension, y_dimension, x_dimension))
+
+    def dump_metrics(self, title, metrics):
+        print("\n" + title)
+        for key in metrics:
+            print(f"\t{key:30s}:{metrics[key]}")
+
+    def score(self, batches, save_arr):
+        pass  # implement in sub-class
+
+    def save(self, to_folder):
+        for (spec, fname) in ((self.input_spec, "input_spec.json"), (self.output_spec, "output_spec.json")):
+            if spec is not None:
+                with open(os.path.join(to_folder, fname), "w") as f:
+                    f.write(json.dumps(spec))
+
+    def load(self, from_folder):
+        for attr, fname in (("input_spec", "input_spec.json"), ("output_spec", "output_spec.json")):
+            path = os.path.join(from_folder, fname)
+            if os.path.exists(path):
+                with open(path) as f:
+                    setattr(self, attr, json.loads(f.read()))
+
+    def train(self, input_variables, output_variable, training_ds, testing_ds, model_path="", training_paths="",
+              testing_paths=""):
+        pass  # implement in sub-class
+
+    def summary(self):
+        pass  # implement in sub-class
+
+    def get_parameters(self):
+        pass  # implement in sub-class
