@@ -104,7 +104,7 @@ def test_train_save_load_apply(tmp_path):
     m2.nr_epochs = 2
     with redirect_stdout(io.StringIO()):
         m2.train(["lowres"], "hires", train, test, model_path=folder)
-    assert m2.history["nr_epochs"] == 5 and len(m2.history["train_loss"]) == 3 + 1  # test_interval 1 -> rows at epoch 0,1
+    assert m2.history["nr_epochs"] == 5 and len(m2.history["train_loss"]) == 3 + 2  # test_interval 1 -> two more rows
 
 
 def test_cli_train_then_apply(tmp_path):
@@ -139,7 +139,8 @@ def test_dataset_errors_match_reference_messages():
     npz = np.load(os.path.join(GOLDEN, "ds_dataset.npz"), allow_pickle=False)
     meta = json.load(open(os.path.join(GOLDEN, "ds_dataset.json")))
     dims = ("n", "c", "y", "x")
-    ds = Dataset({k: DataArray(npz[k], dims=dims if k != "hires" else ("n", "c", "y2", "x2")) for k in ("lowres", "tide", "const", "hires")})
+    ds = Dataset({k: DataArray(npz[k], dims=("n", "c_" + k, "y2" if k == "hires" else "y", "x2" if k == "hires" else "x"))
+                  for k in ("lowres", "tide", "const", "hires")})
     with redirect_stdout(io.StringIO()):
         d = DSDataset(ds, meta["input_names"], "hires")
     assert d.get_normalisation_parameters() == meta["normalisation_parameters"]
@@ -150,9 +151,9 @@ def test_dataset_errors_match_reference_messages():
     np.testing.assert_array_equal(m, npz["mask"][2]); assert lab == meta["labels"][2] and len(d) == 7
     bad = npz["hires"].copy(); bad[1, 0, 2, 3] = np.nan
     with pytest.raises(ValueError) as ei:
-        DSDataset(Dataset({"lowres": ds["lowres"], "hires": DataArray(bad, dims=("n", "c", "y2", "x2"))}), ["lowres"], "hires")
+        DSDataset(Dataset({"lowres": ds["lowres"], "hires": DataArray(bad, dims=("n", "c_hires", "y2", "x2"))}), ["lowres"], "hires")
     assert str(ei.value) == msgs["nan_output_message"]
     bad_in = npz["lowres"].copy(); bad_in[0, 0, 0, 0] = np.nan; bad_in[3, 0, 1, 1] = np.nan
     with pytest.raises(ValueError) as ei:
-        DSDataset(Dataset({"lowres": DataArray(bad_in, dims=dims), "hires": ds["hires"]}), ["lowres"], "hires")
+        DSDataset(Dataset({"lowres": DataArray(bad_in, dims=("n", "c_lowres", "y", "x")), "hires": ds["hires"]}), ["lowres"], "hires")
     assert str(ei.value) == msgs["nan_input_message"]
