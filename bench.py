@@ -132,7 +132,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     spec, enc, dec = build_model(0)
-    eng = HipEngine(spec, FC, LATENT, max_batch=BATCH, device=device)
+    eng = HipEngine(spec, FC, LATENT, max_batch=BATCH, device=device, graph=os.environ.get("CAE_GRAPH", "1") != "0")
     eng.load_state(enc.state_dict(), dec.state_dict())
     eng.set_hyper(lr=1e-3, weight_decay=1e-5)
     x, t = synthetic(N_TRAIN, device, 1234 + rank)

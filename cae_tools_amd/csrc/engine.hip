@@ -266,17 +266,23 @@ bool s2_eligible(const cae_engine* e, const ConvLayer& L) { return e->use_s2 && 
 
 template <int CIN, int COUT, int KH, int KW>
 void s2_fwd_launch(S2Fwd a, hipStream_t s) {
-    const int qx = (a.OW + 1) / 2, qy = (a.OH + 1) / 2;
-    if (qx > 32) {
-        a.tiles_x = (qx + 63) / 64;
-        a.tiles_y = (qy + 3) / 4;
+    // each thread covers 2x2 quads; lanes run along the row
+    const int px = ((a.OW + 1) / 2 + 1) / 2, py = ((a.OH + 1) / 2 + 1) / 2;   // thread columns / rows per image
+    if (px > 32) {
+        a.tiles_x = (px + 63) / 64;
+        a.tiles_y = (py + 3) / 4;
         a.total_tiles = a.B * a.tiles_x * a.tiles_y;
-        hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_s2_fwd2<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
+    } else if (px > 16) {
+        a.tiles_x = (px + 31) / 32;
+        a.tiles_y = (py + 7) / 8;
+        a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+        hipLaunchKernelGGL((k_s2_fwd2<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
     } else {
-        a.tiles_x = (qx + 31) / 32;
-        a.tiles_y = (qy + 7) / 8;
+        a.tiles_x = (px + 15) / 16;
+        a.tiles_y = (py + 15) / 16;
         a.total_tiles = a.B * a.tiles_x * a.tiles_y;
-        hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_s2_fwd2<CIN, COUT, KH, KW, 16>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
     }
 }
 
@@ -291,15 +297,30 @@ void s2_fwd_dispatch(const ConvLayer& L, const S2Fwd& a, hipStream_t s) {
 
 template <int CIN, int COUT, int KH, int KW>
 void s2_bwd_launch(S2Bwd a, hipStream_t s) {
-    constexpr int CT = (CIN % 2 == 0 && CIN != 6) ? 2 : 3;   // input channels per thread
-    constexpr int CG = CIN / CT;                              // ci-groups per workgroup
-    constexpr int PIX = 256 / CG;                             // pixels per tile
-    constexpr int TPX = 32, TPY = PIX / 32;
-    a.tiles_x = (a.W + TPX - 1) / TPX;
-    a.tiles_y = (a.H + TPY - 1) / TPY;
-    a.total_tiles = a.B * a.tiles_x * a.tiles_y;
-    const int grid = a.total_tiles < 1024 ? a.total_tiles : 1024;
-    hipLaunchKernelGGL((k_s2_bwd<CIN, CT, COUT, KH, KW, TPX, TPY>), dim3(grid), dim3(256), 0, s, a);
+    if constexpr (CIN * COUT * KH * KW <= 72) {
+        // direct variant: one input pixel per thread, no LDS staging
+        if (a.W > 32) {
+            a.tiles_x = (a.W + 63) / 64;
+            a.tiles_y = (a.H + 3) / 4;
+            a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+            hipLaunchKernelGGL((k_s2_bwd2<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < 1536 ? a.total_tiles : 1536), dim3(256), 0, s, a);
+        } else {
+            a.tiles_x = (a.W + 31) / 32;
+            a.tiles_y = (a.H + 7) / 8;
+            a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+            hipLaunchKernelGGL((k_s2_bwd2<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < 1536 ? a.total_tiles : 1536), dim3(256), 0, s, a);
+        }
+    } else {
+        constexpr int CT = (CIN % 2 == 0 && CIN != 6) ? 2 : 3;   // input channels per thread
+        constexpr int CG = CIN / CT;                              // ci-groups per workgroup
+        constexpr int PIX = 256 / CG;                             // pixels per tile
+        constexpr int TPX = 32, TPY = PIX / 32;
+        a.tiles_x = (a.W + TPX - 1) / TPX;
+        a.tiles_y = (a.H + TPY - 1) / TPY;
+        a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+        const int grid = a.total_tiles < 1024 ? a.total_tiles : 1024;
+        hipLaunchKernelGGL((k_s2_bwd<CIN, CT, COUT, KH, KW, TPX, TPY>), dim3(grid), dim3(256), 0, s, a);
+    }
 }
 
 void s2_bwd_dispatch(const ConvLayer& L, const S2Bwd& a, hipStream_t s) {

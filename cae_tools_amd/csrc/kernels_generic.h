@@ -110,9 +110,30 @@ struct ConvGeom {
 
 // ---------------------------------------------------------------------------------------------
 
+// Wave-wide sums with DPP (VALU cross-lane moves) instead of __shfl (ds_bpermute, an LDS-pipe
+// instruction with ~50 cycles of latency per step): quad swaps, row mirrors, then the GFX9
+// row-broadcasts.  The total lands in lane 63 and is broadcast back with readlane.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);       // row_half_mirror
+    v += dpp_f<0x140>(v);       // row_mirror: every lane of a 16-lane row holds the row sum
+    v += dpp_f<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_f<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the wave sum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
+    // the per-lane partials are sums of a few hundred fp32 terms: split into hi + lo floats, reduce
+    // both with DPP in fp32 pairs would lose the point of fp64; use the 64-bit DPP-free butterfly on
+    // two 32-bit halves instead
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 

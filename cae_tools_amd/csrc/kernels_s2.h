@@ -47,11 +47,7 @@ struct S2Fwd {
 
 enum S2Epi : int { S2_RAW_STATS = 0, S2_SIGMSE = 1, S2_SIGOUT = 2, S2_RAW = 3 };
 
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum_f(float v) { return wave_sum_dpp(v); }
 
 // store two horizontally adjacent floats; vectorised when the address allows (wave-uniform test:
 // all lanes of a wave share the row, and columns are even)
@@ -413,6 +409,324 @@ __global__ void __launch_bounds__(256) k_s2_bwd(S2Bwd a) {
             const int jj = j - NACC;
             const int ci = gsel * CT + (jj >> 1);
             atomicAdd(&a.stats_in[((size_t)(blockIdx.x & (kStatShards - 1)) * CIN + ci) * 4 + 2 + (jj & 1)], s);
+        }
+    }
+}
+
+
+// =================================================================================================
+// Second-generation kernels for the thinnest layers: instruction count per output, not bytes, was
+// the limit of k_s2_fwd / k_s2_bwd (150 instructions per output pixel, a barrier pair per tile).
+//   * k_s2_fwd2: each thread owns 2x2 quads = a 4x4 output block per channel, from a 3x3 input
+//     neighbourhood per input channel; no branches (clamped addresses + selects), 32-bit offsets,
+//     16-byte stores / target loads when the row pitch allows.
+//   * k_s2_bwd2: no LDS staging and no barriers in the loop: each thread owns one input pixel and
+//     reads its kh x kw gradient patch straight from global memory (the 2-4x overlap between
+//     neighbouring patches is served by L1/L2), so latency is covered by occupancy alone.
+// =================================================================================================
+
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    // 1 / (1 + e^-x); v_rcp_f32 is good to 1 ulp, ample for a [0,1] output compared at 1e-5
+    return __builtin_amdgcn_rcpf(1.0f + expf(-x));
+}
+
+template <int CIN, int COUT, int KH, int KW, int TWL>
+__global__ void __launch_bounds__(256) k_s2_fwd2(S2Fwd a) {
+    constexpr int TROWS = 256 / TWL;  // thread rows per block; each thread covers 2 quad rows x 2 quad cols
+    const int EPI = a.epi;
+    __shared__ float4 cin4[CIN];
+    __shared__ double red[4 * 2 * COUT];
+    bn_consts(a.bn_in, cin4, blockIdx.x == 0);
+    __syncthreads();
+
+    const int tiles = a.tiles_x * a.tiles_y;
+    const unsigned HW = a.H * a.W;
+    double r[2 * COUT];
+#pragma unroll
+    for (int i = 0; i < 2 * COUT; i++) r[i] = 0.0;
+
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const int b = tile / tiles;
+        const int t = tile - b * tiles;
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        const int n0 = 2 * (tx * TWL + (threadIdx.x % TWL));   // first quad column
+        const int m0 = 2 * (ty * TROWS + (threadIdx.x / TWL)); // first quad row
+        const int oy0 = 2 * m0, ox0 = 2 * n0;
+        const bool active = oy0 < a.OH && ox0 < a.OW;
+
+        float acc[COUT][4][4];
+#pragma unroll
+        for (int co = 0; co < COUT; co++) {
+            const float bv = a.bias[co];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) acc[co][y][x] = bv;
+        }
+        // input rows m0-1, m0, m0+1 and columns n0-1, n0, n0+1: clamped offsets + validity masks
+        unsigned roff[3], coff[3];
+        bool rok[3], cok[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const int yy = m0 - 1 + d, xx = n0 - 1 + d;
+            rok[d] = active && yy >= 0 && yy < a.H;
+            cok[d] = xx >= 0 && xx < a.W;
+            roff[d] = (unsigned)min(max(yy, 0), a.H - 1) * (unsigned)a.W;
+            coff[d] = (unsigned)min(max(xx, 0), a.W - 1);
+        }
+        const float* inb = a.in + (size_t)b * CIN * HW;
+#pragma unroll(CIN * COUT * KH * KW <= 80 ? CIN : 1)
+        for (int ci = 0; ci < CIN; ci++) {
+            const float* p = inb + ci * HW;
+            float v[3][3];
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) v[dy][dx] = p[roff[dy] + coff[dx]];
+            if (a.bn_in.mode != BN_NONE) {
+                const float4 k = cin4[ci];
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                    for (int dx = 0; dx < 3; dx++) v[dy][dx] = fmaxf(0.f, fmaf(v[dy][dx] - k.x, k.y, k.z));
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) v[dy][dx] = (rok[dy] && cok[dx]) ? v[dy][dx] : 0.f;
+            const float* wc = a.w + (size_t)ci * COUT * KH * KW;
+#pragma unroll
+            for (int co = 0; co < COUT; co++) {
+#pragma unroll
+                for (int y = 0; y < 4; y++) {        // output row 2*m0 + y: quad row y>>1, parity y&1
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+#pragma unroll
+                            for (int i = 0; i < 2; i++) {
+                                const int ky = (y & 1) + 2 * j, kx = (x & 1) + 2 * i;
+                                if (ky < KH && kx < KW)
+                                    acc[co][y][x] = fmaf(v[(y >> 1) + 1 - j][(x >> 1) + 1 - i],
+                                                         wc[(co * KH + ky) * KW + kx], acc[co][y][x]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!active) continue;
+        // ---- epilogue: 4 rows x 4 columns per output channel
+        const bool vec4 = (a.OW & 3) == 0;   // rows are 16-byte aligned and ox0 is a multiple of 4
+        size_t tb = 0;
+        if (a.target) tb = sample_of(a.perm, a.use_cursor, a.st, b);
+#pragma unroll
+        for (int co = 0; co < COUT; co++) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                const int oy = oy0 + y;
+                if (oy >= a.OH) break;
+                const size_t orow = ((size_t)(b * COUT + co) * a.OH + oy) * a.OW + ox0;
+                float res[4];
+                if (EPI == S2_RAW_STATS || EPI == S2_RAW) {
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        res[x] = acc[co][y][x];
+                        if (ox0 + x < a.OW) { s1 += res[x]; s2 = fmaf(res[x], res[x], s2); }
+                    }
+                } else {
+                    float tv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (a.target) {
+                        const float* tp = a.target + ((tb * COUT + co) * (size_t)a.OH + oy) * a.OW + ox0;
+                        if (vec4) {
+                            const float4 t4 = *reinterpret_cast<const float4*>(tp);
+                            tv[0] = t4.x; tv[1] = t4.y; tv[2] = t4.z; tv[3] = t4.w;
+                        } else {
+#pragma unroll
+                            for (int x = 0; x < 4; x++) tv[x] = (ox0 + x < a.OW) ? tp[x] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const float yh = sigmoid_fast(acc[co][y][x]);
+                        res[x] = yh;
+                        if (a.target && ox0 + x < a.OW) {
+                            const float d = yh - tv[x];
+                            s1 = fmaf(d, d, s1);
+                            if (EPI == S2_SIGMSE) {
+                                res[x] = (2.0f * d * a.inv_count) * (yh * (1.0f - yh));
+                                s2 += res[x];
+                            }
+                        }
+                    }
+                }
+                if (a.out) {
+                    float* o = a.out + orow;
+                    if (vec4) {
+                        *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < 4; x++)
+                            if (ox0 + x < a.OW) o[x] = res[x];
+                    }
+                }
+            }
+            if (EPI == S2_RAW_STATS) {
+                r[2 * co] += (double)s1;
+                r[2 * co + 1] += (double)s2;
+            } else if (EPI != S2_RAW) {
+                r[2 * co] += (double)s1 * (double)a.inv_count;
+                r[2 * co + 1] += (double)s2;
+            }
+        }
+    }
+
+    if (EPI == S2_RAW) return;
+    if (EPI == S2_SIGOUT && !a.target) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 2 * COUT; i++) {
+        const double s = wave_sum(r[i]);
+        if (lane == 0) red[wv * 2 * COUT + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * COUT) {
+        const int i = threadIdx.x;
+        const double s = red[i] + red[2 * COUT + i] + red[4 * COUT + i] + red[6 * COUT + i];
+        const int co = i >> 1;
+        const int shard = blockIdx.x & (kStatShards - 1);
+        if (EPI == S2_RAW_STATS) {
+            atomicAdd(&a.stats[((size_t)shard * COUT + co) * 4 + (i & 1)], s);
+        } else if ((i & 1) == 0) {
+            atomicAdd(&a.losses[(size_t)a.st->loss_slot * kStatShards + shard], s);
+        } else if (EPI == S2_SIGMSE) {
+            atomicAdd(&a.bias_acc[(size_t)shard * a.bias_stride + co], s);
+        }
+    }
+}
+
+// ---- direct (LDS-free) fused backward for CIN <= 4 ------------------------------------------------
+template <int CIN, int COUT, int KH, int KW, int TWL>
+__global__ void __launch_bounds__(256) k_s2_bwd2(S2Bwd a) {
+    constexpr int TROWS = 256 / TWL;
+    constexpr int NACC = CIN * COUT * KH * KW;
+    constexpr int NRED = NACC + 2 * CIN;
+    __shared__ float4 cout4[COUT];
+    __shared__ float4 cin4[CIN];
+    __shared__ float redf[4 * NRED];
+
+    bn_consts(a.bn_out, cout4, false);
+    bn_consts(a.bn_in, cin4, false);
+    if (blockIdx.x == 0 && a.bg.stats) {
+        for (int c = threadIdx.x; c < a.bg.C; c += 256) {
+            double sb = 0.0, sg = 0.0;
+            for (int sh = 0; sh < kStatShards; sh++) {
+                sb += a.bg.stats[((size_t)sh * a.bg.C + c) * 4 + 2];
+                sg += a.bg.stats[((size_t)sh * a.bg.C + c) * 4 + 3];
+            }
+            a.bg.beta_acc[c] = sb * a.bg.scale;
+            a.bg.gamma_acc[c] = sg * a.bg.scale;
+        }
+    }
+    __syncthreads();
+
+    const int tiles = a.tiles_x * a.tiles_y;
+    const unsigned HW = a.H * a.W, OHW = a.OH * a.OW;
+    float dw[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) dw[i] = 0.f;
+    float d1[CIN], d2[CIN];
+#pragma unroll
+    for (int i = 0; i < CIN; i++) d1[i] = d2[i] = 0.f;
+
+    for (int t = blockIdx.x; t < a.total_tiles; t += gridDim.x) {
+        const int b = t / tiles;
+        const int tt = t - b * tiles;
+        const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+        const int x = tx * TWL + (threadIdx.x % TWL);
+        const int y = ty * TROWS + (threadIdx.x / TWL);
+        if (y >= a.H || x >= a.W) continue;
+        const unsigned poff = (unsigned)y * a.W + x;
+        float av[CIN], yraw[CIN], ga[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++) {
+            yraw[ci] = a.ain[(size_t)(b * CIN + ci) * HW + poff];
+            av[ci] = yraw[ci];
+            if (a.bn_in.mode != BN_NONE) {
+                const float4 k = cin4[ci];
+                av[ci] = fmaxf(0.f, fmaf(yraw[ci] - k.x, k.y, k.z));
+            }
+            ga[ci] = 0.f;
+        }
+        const unsigned pbase = (unsigned)(2 * y) * a.OW + 2 * x;
+#pragma unroll
+        for (int co = 0; co < COUT; co++) {
+            const float* gp = a.g + (size_t)(b * COUT + co) * OHW + pbase;
+            const float* yp = a.yout ? a.yout + (size_t)(b * COUT + co) * OHW + pbase : nullptr;
+            float p[KH][KW];
+#pragma unroll
+            for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+                for (int kx = 0; kx < KW; kx++) p[ky][kx] = gp[ky * a.OW + kx];
+            if (a.bn_out.mode == BN_BWD) {
+                const float4 k = cout4[co];
+#pragma unroll
+                for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < KW; kx++)
+                        p[ky][kx] = k.y * p[ky][kx] - k.z - (yp[ky * a.OW + kx] - k.x) * k.w;
+            }
+#pragma unroll
+            for (int ci = 0; ci < CIN; ci++) {
+                const float* wc = a.w + ((size_t)ci * COUT + co) * KH * KW;
+#pragma unroll
+                for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < KW; kx++) {
+                        ga[ci] = fmaf(p[ky][kx], wc[ky * KW + kx], ga[ci]);
+                        dw[((ci * COUT + co) * KH + ky) * KW + kx] =
+                            fmaf(av[ci], p[ky][kx], dw[((ci * COUT + co) * KH + ky) * KW + kx]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++) {
+            float gv = ga[ci];
+            if (a.bn_in.mode != BN_NONE) {
+                const float4 k = cin4[ci];
+                const float d = yraw[ci] - k.x;
+                gv = fmaf(d, k.y, k.z) > 0.f ? gv : 0.f;
+                d1[ci] += gv;
+                d2[ci] = fmaf(gv, d * k.w, d2[ci]);
+            }
+            a.gin[(size_t)(b * CIN + ci) * HW + poff] = gv;
+        }
+    }
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NACC; i++) {
+        const float s = wave_sum_f(dw[i]);
+        if (lane == 0) redf[wv * NRED + i] = s;
+    }
+#pragma unroll
+    for (int c = 0; c < CIN; c++) {
+        const float s1 = wave_sum_f(d1[c]), s2 = wave_sum_f(d2[c]);
+        if (lane == 0) {
+            redf[wv * NRED + NACC + 2 * c] = s1;
+            redf[wv * NRED + NACC + 2 * c + 1] = s2;
+        }
+    }
+    __syncthreads();
+    const int shard = blockIdx.x & (kStatShards - 1);
+    for (int j = threadIdx.x; j < NRED; j += 256) {
+        const double s = (double)redf[j] + (double)redf[NRED + j] + (double)redf[2 * NRED + j] + (double)redf[3 * NRED + j];
+        if (j < NACC) {
+            atomicAdd(&a.wacc[(size_t)shard * a.wacc_stride + j], s);
+        } else if (a.stats_in) {
+            const int jj = j - NACC;
+            atomicAdd(&a.stats_in[((size_t)shard * CIN + (jj >> 1)) * 4 + 2 + (jj & 1)], s);
         }
     }
 }
