@@ -472,10 +472,12 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             f.in = small.p; f.bn_in = bns; f.w = e->params + L.w_off; f.bias = e->params + L.b_off;
             f.out = ep.out; f.stats = a.train ? ep.stats : nullptr;
             const int mtiles = (B * f.QH * f.QW + 15) / 16;
-            f.tiles_per_wave = mtiles >= 4096 ? 4 : (mtiles >= 1024 ? 2 : 1);
-            dim3 grid((mtiles + 4 * f.tiles_per_wave - 1) / (4 * f.tiles_per_wave), 4, (L.cout + 15) / 16);
+            f.ksplit = L.cin >= 48 ? 4 : (L.cin >= 24 ? 2 : 1);
+            f.tiles_per_wave = mtiles >= 8192 ? 2 : 1;
+            const int per_block = (4 / f.ksplit) * f.tiles_per_wave;
+            dim3 grid((mtiles + per_block - 1) / per_block, 4, (L.cout + 15) / 16);
             ProfScope _p(e, a.train ? "ig_convt_fwd" : "ig_convt_eval", (int)l, f4((double)B * (L.in_elems() + L.out_elems())));
-            hipLaunchKernelGGL(k_ig_fwd_s2, grid, dim3(256), 32 * sizeof(float) + (size_t)(L.cin + 1) * sizeof(float4), s, f);
+            hipLaunchKernelGGL(k_ig_fwd_s2, grid, dim3(256), (32 + 1024) * sizeof(float) + (size_t)(L.cin + 1) * sizeof(float4), s, f);
             continue;
         }
         dim3 grid(grid1((int64_t)B * L.hout * L.wout), L.cout);
@@ -592,9 +594,12 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                     f.stats_prev = e->bn_stats(P.bn_index);
                 }
                 const int mtiles = (B * L.hin * L.win + 15) / 16;
-                f.tiles_per_wave = mtiles >= 4096 ? 4 : (mtiles >= 1024 ? 2 : 1);
-                dim3 grid((mtiles + 4 * f.tiles_per_wave - 1) / (4 * f.tiles_per_wave), (L.cin + 15) / 16);
-                const size_t lds = 32 * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4) +
+                const int ksteps = (L.cout * L.kh * L.kw + 3) / 4;
+                f.ksplit = ksteps >= 40 ? 4 : (ksteps >= 20 ? 2 : 1);
+                f.tiles_per_wave = mtiles >= 8192 ? 2 : 1;
+                const int per_block = (4 / f.ksplit) * f.tiles_per_wave;
+                dim3 grid((mtiles + per_block - 1) / per_block, (L.cin + 15) / 16);
+                const size_t lds = (32 + 1024) * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4) +
                                    (size_t)L.cout * L.kh * L.kw * sizeof(int);
                 ProfScope _p(e, "ig_convt_dgrad", l,
                              f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));

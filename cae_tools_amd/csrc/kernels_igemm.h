@@ -24,6 +24,7 @@ namespace cae {
 struct IgFwd {
     int B, Cin, H, W, Cout, OH, OW, KH, KW, QH, QW;
     int tiles_per_wave;
+    int ksplit;            // 1, 2 or 4: waves of a workgroup that share one M-tile and split the channels
     const float* in;
     BnDesc bn_in;
     const float* w;
@@ -36,7 +37,8 @@ struct IgFwd {
 __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
     extern __shared__ double lds_d[];
     float* lstat = reinterpret_cast<float*>(lds_d);  // [16 channels][2]
-    float4* cin4 = reinterpret_cast<float4*>(lstat + 32);
+    float* part = lstat + 32;                        // [4 waves][256] split-K partial tiles
+    float4* cin4 = reinterpret_cast<float4*>(part + 1024);
     bn_consts(a.bn_in, cin4, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
     if (threadIdx.x < 32) lstat[threadIdx.x] = 0.f;
     __syncthreads();
@@ -56,12 +58,16 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
     const float bias = co < a.Cout ? a.bias[co] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 
+    const int KS = a.ksplit;
+    const int mslot = wv / KS, kslot = wv - mslot * KS;       // which M-tile of the workgroup, which K slice
+    const int cper = ((a.Cin + KS - 1) / KS + 7) & ~7;        // channels per K slice (multiple of the unroll)
+    const int cbeg = kslot * cper, cend = min(a.Cin, cbeg + cper);
     for (int tt = 0; tt < a.tiles_per_wave; tt++) {
-        const int tile = (blockIdx.x * 4 + wv) * a.tiles_per_wave + tt;
-        if (tile * 16 >= M) break;
+        const int tile = (blockIdx.x * (4 / KS) + mslot) * a.tiles_per_wave + tt;
+        const bool tile_ok = tile * 16 < M;                   // uniform per wave; no early exit: barriers below
         // A row of this lane: quad m -> (b, qm, qn)
         const int m = tile * 16 + r;
-        bool a_ok = m < M;
+        bool a_ok = tile_ok && m < M;
         const int b = m / QQ, rem = m - b * QQ;
         const int qm = rem / a.QW, qn = rem - qm * a.QW;
         const int iy = qm - j, ix = qn - i;
@@ -69,12 +75,12 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
         const float* ap = a.in + (size_t)b * a.Cin * HW + (size_t)iy * a.W + ix;
 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int c0 = 0; c0 < a.Cin; c0 += 8) {
+        for (int c0 = cbeg; c0 < cend; c0 += 8) {
             float av[8], bv[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int ci = c0 + u;
-                const bool c_ok = ci < a.Cin;
+                const bool c_ok = ci < cend;
                 av[u] = (a_ok && c_ok) ? ap[(size_t)ci * HW] : 0.f;
                 bv[u] = (b_ok && c_ok) ? bp[(size_t)ci * b_step] : 0.f;
                 if (a.bn_in.mode != BN_NONE && a_ok && c_ok) {
@@ -85,8 +91,19 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
 #pragma unroll
             for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
         }
+        if (KS > 1) {   // combine the K slices of this M-tile in the slice-0 wave
+            __syncthreads();
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) part[wv * 256 + jj * 64 + lane] = acc[jj];
+            __syncthreads();
+            if (kslot == 0) {
+                for (int o = 1; o < KS; o++)
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) acc[jj] += part[(wv + o) * 256 + jj * 64 + lane];
+            }
+        }
         // epilogue: rows 4q..4q+3 of the tile, column co
-        if (co < a.Cout) {
+        if (co < a.Cout && kslot == 0 && tile_ok) {
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
                 const int cm = tile * 16 + q * 4 + jj;
@@ -125,6 +142,7 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
 struct IgDgrad {
     int B, Cin, H, W, Cout, OH, OW, KH, KW, S;
     int tiles_per_wave;
+    int ksplit;            // 1, 2 or 4 waves share one M-tile and split K = Cout*kh*kw
     const float* g;        // (B,Cout,OH,OW) masked gradient (or dL/dy of the last layer)
     const float* yout;     // raw forward output of this layer (BN_BWD) or nullptr
     BnDesc bn_out;
@@ -140,7 +158,8 @@ __global__ void __launch_bounds__(256) k_ig_dgrad(IgDgrad a) {
     extern __shared__ double lds_d[];
     const int K = a.Cout * a.KH * a.KW;
     float* lstat = reinterpret_cast<float*>(lds_d);               // [16][2]
-    float4* cout4 = reinterpret_cast<float4*>(lstat + 32);        // [Cout]
+    float* part = lstat + 32;                                     // [4][256] split-K partial tiles
+    float4* cout4 = reinterpret_cast<float4*>(part + 1024);       // [Cout]
     float4* cprev4 = cout4 + a.Cout;                              // [Cin]
     int* koff = reinterpret_cast<int*>(cprev4 + a.Cin);           // [K] offset of tap k inside one image of gy
     bn_consts(a.bn_out, cout4, false);
@@ -163,22 +182,26 @@ __global__ void __launch_bounds__(256) k_ig_dgrad(IgDgrad a) {
     const int khw = a.KH * a.KW;
     float d1 = 0.f, d2 = 0.f;
 
+    const int KS = a.ksplit;
+    const int mslot = wv / KS, kslot = wv - mslot * KS;
+    const int kper = (((K + 3) / 4 + KS - 1) / KS + 7) / 8 * 32;   // k per slice, multiple of 32 (8 MFMA steps)
+    const int kbeg = kslot * kper, kend = min(K, kbeg + kper);
     for (int tt = 0; tt < a.tiles_per_wave; tt++) {
-        const int tile = (blockIdx.x * 4 + wv) * a.tiles_per_wave + tt;
-        if (tile * 16 >= M) break;
+        const int tile = (blockIdx.x * (4 / KS) + mslot) * a.tiles_per_wave + tt;
+        const bool tile_ok = tile * 16 < M;
         const int m = tile * 16 + r;
-        const bool a_ok = m < M;
+        const bool a_ok = tile_ok && m < M;
         const int b = m / HW, rem = m - b * HW;
         const int y = rem / a.W, x = rem - y * a.W;
         const size_t abase = (size_t)b * a.Cout * a.OH * a.OW + (size_t)(a.S * y) * a.OW + a.S * x;
 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < K; k0 += 32) {
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
             float av[8], bv[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int k = k0 + 4 * u + q;
-                const bool k_ok = k < K;
+                const bool k_ok = k < kend;
                 float v = 0.f;
                 if (a_ok && k_ok) {
                     const size_t off = abase + koff[k];
@@ -194,7 +217,18 @@ __global__ void __launch_bounds__(256) k_ig_dgrad(IgDgrad a) {
 #pragma unroll
             for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
         }
-        if (b_ok) {
+        if (KS > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) part[wv * 256 + jj * 64 + lane] = acc[jj];
+            __syncthreads();
+            if (kslot == 0) {
+                for (int o = 1; o < KS; o++)
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) acc[jj] += part[(wv + o) * 256 + jj * 64 + lane];
+            }
+        }
+        if (b_ok && kslot == 0 && tile_ok) {
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
                 const int cm = tile * 16 + q * 4 + jj;
