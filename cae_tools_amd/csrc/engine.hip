@@ -91,6 +91,10 @@ struct cae_engine {
     float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr, *bufs = nullptr;
     char* ws = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;            // weight-gradient kernels run here, beside the dgrad chain
+    std::vector<hipEvent_t> fork_events;   // one per fork/join point of a step
+    size_t fork_used = 0;
+    bool use_side = false;  // measured: 397 vs 363 us/step - cross-queue fork/join costs more than it overlaps
     Hyper hp{1e-3, 0.9, 0.999, 1e-8, 1e-5};
     const float* ds_x[2] = {nullptr, nullptr};
     const float* ds_t[2] = {nullptr, nullptr};
@@ -215,23 +219,53 @@ int wgrad_ppb(int64_t positions, int64_t nweights) {
 
 enum Op { OP_TRAIN = 1, OP_FWDBWD = 2, OP_EVAL = 3, OP_ADAM = 4 };
 
+StepTail step_tail_of(cae_engine* e, int batch_inc, int slot_inc) {
+    StepTail t;
+    memset(&t, 0, sizeof t);
+    t.zero_extra = reinterpret_cast<double*>(e->ws + e->off_zero_begin);
+    t.zero_extra_n = (e->off_gradacc - e->off_zero_begin) / (long long)sizeof(double);
+    t.acc_rw = e->gradacc();
+    t.shard_rw = e->sgacc();
+    t.st = e->state();
+    t.batch_inc = batch_inc;
+    t.slot_inc = slot_inc;
+    return t;
+}
+
 // Brackets one launch with HIP events on the engine's stream while profiling is on.
 // `bytes` = algorithmic bytes of the launch: every operand tensor read once, every result written once.
 struct ProfScope {
     cae_engine* e;
+    hipStream_t st;
     int idx = -1;
-    ProfScope(cae_engine* e_, const char* name, int layer, double bytes) : e(e_) {
+    ProfScope(cae_engine* e_, const char* name, int layer, double bytes, hipStream_t on = nullptr) : e(e_) {
+        st = on ? on : e->stream;
         if (!e->profiling) return;
         cae_engine::ProfRec r{name, layer, bytes, nullptr, nullptr};
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
-        (void)hipEventRecord(r.e0, e->stream);
+        (void)hipEventRecord(r.e0, st);
         e->prof.push_back(r);
         idx = (int)e->prof.size() - 1;
     }
     ~ProfScope() {
-        if (idx >= 0) (void)hipEventRecord(e->prof[idx].e1, e->stream);
+        if (idx >= 0) (void)hipEventRecord(e->prof[idx].e1, st);
     }
 };
+
+// order `to` after everything enqueued so far on `from` (works eagerly and inside stream capture,
+// where it is what pulls the side stream into the captured graph)
+int stream_after(cae_engine* e, hipStream_t from, hipStream_t to) {
+    if (from == to) return CAE_OK;
+    if (e->fork_used == e->fork_events.size()) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e->fork_events.push_back(ev);
+    }
+    hipEvent_t ev = e->fork_events[e->fork_used++];
+    HIP_TRY(hipEventRecord(ev, from));
+    HIP_TRY(hipStreamWaitEvent(to, ev, 0));
+    return CAE_OK;
+}
 inline double f4(double n) { return 4.0 * n; }
 
 // ---- the step, as a sequence of launches on e->stream -------------------------------------------
@@ -348,6 +382,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             big = src_plain(a.x_direct ? a.x_direct : e->ds_x[a.which], L.cin, L.hin, L.win);
             big.perm = a.x_direct ? nullptr : a.perm;
             big.use_cursor = a.x_direct ? 0 : 1;
+            big.bump_adam = a.train ? 1 : 0;
         } else {
             const ConvLayer& P = e->enc[l - 1];
             big = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
@@ -491,6 +526,9 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
 
 int launch_backward(cae_engine* e, const StepArgs& a) {
     hipStream_t s = e->stream;
+    // weight gradients only feed Adam: they run on the side stream, concurrently with the chain of
+    // input-gradient kernels; every section first orders the side stream after the producer of gy
+    hipStream_t ws = (e->use_side && e->side && e->stream) ? e->side : e->stream;
     const int B = a.batch;
     const StepState* st = e->state();
     double* acc = e->gradacc();
@@ -552,59 +590,55 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             continue;
         }
         if (e->use_s2) {
-            {
-                IgWgrad f;
-                memset(&f, 0, sizeof f);
-                f.B = B; f.Cin = L.cin; f.H = L.hin; f.W = L.win; f.Cout = L.cout; f.OH = L.hout; f.OW = L.wout;
-                f.KH = L.kh; f.KW = L.kw; f.S = L.stride;
-                f.ain = ain.p; f.bn_in = bna; f.g = gy.p; f.yout = gy.q; f.bn_out = bng;
-                f.wacc = acc + L.w_off;
-                if (L.has_bn) {
-                    f.bg.stats = e->bn_stats(L.bn_index);
-                    f.bg.gamma_acc = acc + L.gamma_off;
-                    f.bg.beta_acc = acc + L.beta_off;
-                    f.bg.C = L.cout;
-                    f.bg.scale = 1.0;
-                }
-                const int tiles = ((L.cin + 15) / 16) * ((L.cout * L.kh * L.kw + 15) / 16);
-                const int steps = (B * L.hin * L.win + 3) / 4;
-                int chunks = 1024 / tiles;
-                if (chunks < 1) chunks = 1;
-                int per = (steps + chunks - 1) / chunks;
-                per = (per + 31) / 32 * 32;
-                chunks = (steps + per - 1) / per;
-                f.ksteps_per_block = per;
-                ProfScope _p(e, "ig_convt_wgrad", l, f4((double)B * (L.in_elems() + L.out_elems() * (last ? 1.0 : 2.0))));
-                hipLaunchKernelGGL(k_ig_wgrad, dim3(tiles, chunks), dim3(256),
-                                   1024 * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4), s, f);
+            IgWgrad fw;
+            memset(&fw, 0, sizeof fw);
+            fw.B = B; fw.Cin = L.cin; fw.H = L.hin; fw.W = L.win; fw.Cout = L.cout; fw.OH = L.hout; fw.OW = L.wout;
+            fw.KH = L.kh; fw.KW = L.kw; fw.S = L.stride;
+            fw.ain = ain.p; fw.bn_in = bna; fw.g = gy.p; fw.yout = gy.q; fw.bn_out = bng;
+            fw.wacc = acc + L.w_off;
+            if (L.has_bn) {
+                fw.bg.stats = e->bn_stats(L.bn_index);
+                fw.bg.gamma_acc = acc + L.gamma_off;
+                fw.bg.beta_acc = acc + L.beta_off;
+                fw.bg.C = L.cout;
+                fw.bg.scale = 1.0;
             }
-            {
-                IgDgrad f;
-                memset(&f, 0, sizeof f);
-                f.B = B; f.Cin = L.cin; f.H = L.hin; f.W = L.win; f.Cout = L.cout; f.OH = L.hout; f.OW = L.wout;
-                f.KH = L.kh; f.KW = L.kw; f.S = L.stride;
-                f.g = gy.p; f.yout = gy.q; f.bn_out = bng; f.w = e->params + L.w_off;
-                if (l == 0) {
-                    f.gin = e->fptr(e->fc[3].grad_off);
-                } else {
-                    const ConvLayer& P = e->dec[l - 1];
-                    f.gin = e->fptr(P.grad_off);
-                    f.yprev = e->fptr(P.act_off);
-                    f.bn_prev = bn_of(e, P, BN_SAVED, 0, 0);
-                    f.stats_prev = e->bn_stats(P.bn_index);
-                }
-                const int mtiles = (B * L.hin * L.win + 15) / 16;
-                const int ksteps = (L.cout * L.kh * L.kw + 3) / 4;
-                f.ksplit = ksteps >= 40 ? 4 : (ksteps >= 20 ? 2 : 1);
-                f.tiles_per_wave = mtiles >= 8192 ? 2 : 1;
-                const int per_block = (4 / f.ksplit) * f.tiles_per_wave;
-                dim3 grid((mtiles + per_block - 1) / per_block, (L.cin + 15) / 16);
-                const size_t lds = (32 + 1024) * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4) +
-                                   (size_t)L.cout * L.kh * L.kw * sizeof(int);
-                ProfScope _p(e, "ig_convt_dgrad", l,
-                             f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));
-                hipLaunchKernelGGL(k_ig_dgrad, grid, dim3(256), lds, s, f);
+            const int wtiles = ((L.cin + 15) / 16) * ((L.cout * L.kh * L.kw + 15) / 16);
+            const int steps = (B * L.hin * L.win + 3) / 4;
+            int chunks = 1024 / wtiles;
+            if (chunks < 1) chunks = 1;
+            int per = (steps + chunks - 1) / chunks;
+            per = (per + 31) / 32 * 32;
+            chunks = (steps + per - 1) / per;
+            fw.ksteps_per_block = per;
+
+            IgDgrad fd;
+            memset(&fd, 0, sizeof fd);
+            fd.B = B; fd.Cin = L.cin; fd.H = L.hin; fd.W = L.win; fd.Cout = L.cout; fd.OH = L.hout; fd.OW = L.wout;
+            fd.KH = L.kh; fd.KW = L.kw; fd.S = L.stride;
+            fd.g = gy.p; fd.yout = gy.q; fd.bn_out = bng; fd.w = e->params + L.w_off;
+            if (l == 0) {
+                fd.gin = e->fptr(e->fc[3].grad_off);
+            } else {
+                const ConvLayer& P = e->dec[l - 1];
+                fd.gin = e->fptr(P.grad_off);
+                fd.yprev = e->fptr(P.act_off);
+                fd.bn_prev = bn_of(e, P, BN_SAVED, 0, 0);
+                fd.stats_prev = e->bn_stats(P.bn_index);
             }
+            const int mtiles = (B * L.hin * L.win + 15) / 16;
+            const int ksteps = (L.cout * L.kh * L.kw + 3) / 4;
+            fd.ksplit = ksteps >= 40 ? 4 : (ksteps >= 20 ? 2 : 1);
+            fd.tiles_per_wave = mtiles >= 8192 ? 2 : 1;
+            const int per_block = (4 / fd.ksplit) * fd.tiles_per_wave;
+            const int d_gx = (mtiles + per_block - 1) / per_block, d_gy = (L.cin + 15) / 16;
+            const size_t lds_d = (32 + 1024) * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4) +
+                                 (size_t)L.cout * L.kh * L.kw * sizeof(int);
+            const size_t lds_w = 1024 * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4);
+            ProfScope _p(e, "ig_convt_bwd_pair", l,
+                         f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));
+            hipLaunchKernelGGL(k_ig_bwd_pair, dim3(wtiles * chunks + d_gx * d_gy), dim3(256), lds_d > lds_w ? lds_d : lds_w, s,
+                               fw, fd, wtiles, chunks, d_gx);
             continue;
         }
         // weight gradient (+ BN parameter gradients of this layer)
@@ -657,50 +691,52 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             const float* in = i == 0 ? e->fptr(P.act_off) : e->fptr(e->fc[i - 1].act_off);
             BnDesc bni = i == 0 ? bn_of(e, P, BN_SAVED, 0, 0) : bn_none();
             if (e->use_s2) {
-                {   // dW[o][i] = sum_b gout[b][o] * in[b][i], db[o] = sum_b gout[b][o]  (ones column)
-                    ProfScope _p(e, "linear_wgrad_mfma", i, f4((double)B * (F.nin + F.nout)) + 8.0 * F.nin * F.nout);
-                    GemmArgs ga;
-                    memset(&ga, 0, sizeof ga);
-                    ga.M = F.nout; ga.N = F.nin + 1; ga.K = B;
-                    ga.A = gout; ga.sa_m = 1; ga.sa_k = F.nout;       // A[m=o][k=b] = gout[b][o]
-                    ga.B = in; ga.sb_k = F.nin; ga.sb_n = 1;          // B[k=b][n=i] = in[b][i]
-                    ga.epi = GE_ACC64;
-                    ga.accW = acc + F.w_off; ga.accB = acc + F.b_off; ga.ones_col = 1;
-                    if (i == 0) {
-                        // its input carries the BatchNorm+ReLU transform on the B side; tiny (C*y*x x fc):
-                        // the generic kernel handles it
+                // weight gradient: dW[o][i] = sum_b gout[b][o] * in[b][i], db[o] = sum_b gout[b][o] (ones column)
+                GemmArgs gw;
+                memset(&gw, 0, sizeof gw);
+                gw.M = F.nout; gw.N = F.nin + 1; gw.K = B;
+                gw.A = gout; gw.sa_m = 1; gw.sa_k = F.nout;       // A[m=o][k=b] = gout[b][o]
+                gw.B = in; gw.sb_k = F.nin; gw.sb_n = 1;          // B[k=b][n=i] = in[b][i]
+                gw.epi = GE_ACC64;
+                gw.accW = acc + F.w_off; gw.accB = acc + F.b_off; gw.ones_col = 1;
+                // input gradient: gin[b][i] = mask( sum_o gout[b][o] * W[o][i] )
+                GemmArgs gd;
+                memset(&gd, 0, sizeof gd);
+                gd.M = B; gd.N = F.nin; gd.K = F.nout;
+                gd.A = gout; gd.sa_m = F.nout; gd.sa_k = 1;
+                gd.B = e->params + F.w_off; gd.sb_k = F.nin; gd.sb_n = 1;   // B[k=o][n=i] = W[o][i]
+                gd.sc_m = F.nin; gd.sc_n = 1;
+                size_t lds = gemm_lds(0);
+                if (i > 0) {
+                    const FcLayer& G = e->fc[i - 1];
+                    gd.C = e->fptr(G.grad_off);
+                    gd.epi = G.relu ? GE_RELU_MASK : GE_STORE;
+                    gd.H = e->fptr(G.act_off);
+                } else {
+                    gd.C = e->fptr(P.grad_off);
+                    gd.epi = GE_BN_MASK;
+                    gd.H = e->fptr(P.act_off);
+                    gd.bn_c = bni; gd.hw_c = hw;
+                    gd.stats_c = e->bn_stats(P.bn_index);
+                    lds = gemm_lds(P.cout);
+                }
+                const int tiles_d = ((gd.M + 15) / 16) * ((gd.N + 15) / 16);
+                if (i == 0) {
+                    // the first encoder Linear's input carries BatchNorm+ReLU on the B side of the weight
+                    // gradient: the generic kernel handles that one (36 x fc_size values)
+                    {
+                        ProfScope _p(e, "linear_wgrad", i, f4((double)B * (F.nin + F.nout)) + 8.0 * F.nin * F.nout);
                         hipLaunchKernelGGL(k_lin_wgrad, dim3(grid1((int64_t)F.nin * F.nout)), dim3(256),
                                            lds_bytes(P.cout, 0), s, B, F.nin, F.nout, gout, in, bni, hw,
                                            acc + F.w_off, acc + F.b_off);
-                    } else {
-                        const int tiles = ((ga.M + 15) / 16) * ((ga.N + 15) / 16);
-                        hipLaunchKernelGGL(k_gemm16, dim3(tiles), dim3(256), gemm_lds(0), s, ga);
                     }
-                }
-                {   // gin[b][i] = mask( sum_o gout[b][o] * W[o][i] )
                     ProfScope _p(e, "linear_dgrad_mfma", i, f4((double)B * (2.0 * F.nin + F.nout) + (double)F.nin * F.nout));
-                    GemmArgs ga;
-                    memset(&ga, 0, sizeof ga);
-                    ga.M = B; ga.N = F.nin; ga.K = F.nout;
-                    ga.A = gout; ga.sa_m = F.nout; ga.sa_k = 1;
-                    ga.B = e->params + F.w_off; ga.sb_k = F.nin; ga.sb_n = 1;   // B[k=o][n=i] = W[o][i]
-                    ga.sc_m = F.nin; ga.sc_n = 1;
-                    size_t lds = gemm_lds(0);
-                    if (i > 0) {
-                        const FcLayer& G = e->fc[i - 1];
-                        ga.C = e->fptr(G.grad_off);
-                        ga.epi = G.relu ? GE_RELU_MASK : GE_STORE;
-                        ga.H = e->fptr(G.act_off);
-                    } else {
-                        ga.C = e->fptr(P.grad_off);
-                        ga.epi = GE_BN_MASK;
-                        ga.H = e->fptr(P.act_off);
-                        ga.bn_c = bni; ga.hw_c = hw;
-                        ga.stats_c = e->bn_stats(P.bn_index);
-                        lds = gemm_lds(P.cout);
-                    }
-                    const int tiles = ((ga.M + 15) / 16) * ((ga.N + 15) / 16);
-                    hipLaunchKernelGGL(k_gemm16, dim3(tiles), dim3(256), lds, s, ga);
+                    hipLaunchKernelGGL(k_gemm16, dim3(tiles_d), dim3(256), lds, s, gd);
+                } else {
+                    const int tiles_w = ((gw.M + 15) / 16) * ((gw.N + 15) / 16);
+                    ProfScope _p(e, "linear_bwd_pair_mfma", i,
+                                 f4((double)B * (3.0 * F.nin + 2.0 * F.nout) + (double)F.nin * F.nout) + 8.0 * F.nin * F.nout);
+                    hipLaunchKernelGGL(k_gemm16_pair, dim3(tiles_w + tiles_d), dim3(256), lds, s, gw, gd, tiles_w);
                 }
                 continue;
             }
@@ -755,8 +791,9 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             bg.C = L.cout;
             bg.scale = 1.0;
             dim3 grid((unsigned)nw, (unsigned)((pos + ppb - 1) / ppb));
-            ProfScope _p(e, "enc_conv_wgrad", l, f4((double)B * (L.in_elems() + 2.0 * L.out_elems())));
-            hipLaunchKernelGGL(k_wgrad, grid, dim3(256), lds_bytes(L.cout, L.cin), s, g, gy, bng, ain, bna,
+            if (int rc = stream_after(e, s, ws)) return rc;
+            ProfScope _p(e, "enc_conv_wgrad", l, f4((double)B * (L.in_elems() + 2.0 * L.out_elems())), ws);
+            hipLaunchKernelGGL(k_wgrad, grid, dim3(256), lds_bytes(L.cout, L.cin), ws, g, gy, bng, ain, bna,
                                acc + L.w_off, ppb, bg, st);
         }
         if (l > 0) {
@@ -773,16 +810,16 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                                (const float*)nullptr, ep, bne, st);
         }
     }
+    if (int rc = stream_after(e, ws, s)) return rc;   // join: Adam needs every weight gradient
     return CAE_OK;
 }
 
 int launch_op(cae_engine* e, int op, const StepArgs& a) {
     hipStream_t s = e->stream;
+    e->fork_used = 0;
     if (op == OP_TRAIN || op == OP_FWDBWD) {
-        {
-            ProfScope _p(e, "zero_accumulators", 0, (double)(e->off_zero_end - e->off_zero_begin));
-            HIP_TRY(hipMemsetAsync(e->ws + e->off_zero_begin, 0, (size_t)(e->off_zero_end - e->off_zero_begin), s));
-        }
+        // the accumulators were zeroed by the previous step's last kernel (k_adam / k_acc_to_f32) or by
+        // the caller's zero-filled workspace on the very first step
         int rc = launch_forward(e, a);
         if (rc) return rc;
         rc = launch_backward(e, a);
@@ -790,23 +827,23 @@ int launch_op(cae_engine* e, int op, const StepArgs& a) {
         if (op == OP_TRAIN) {
             ProfScope _p(e, "adam", 0, 32.0 * e->n_param);
             hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
-                               (const double*)e->gradacc(), (const float*)nullptr, e->m, e->v, e->hp,
-                               (const StepState*)e->state(), e->shard_segs());
-            hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), a.batch, 1, 1);
+                               (const float*)nullptr, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(),
+                               step_tail_of(e, a.batch, 1), 0);
         } else {
-            hipLaunchKernelGGL(k_acc_to_f32, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param,
-                               (const double*)e->gradacc(), e->grads, e->shard_segs());
-            hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), a.batch, 1, 0);
+            hipLaunchKernelGGL(k_acc_to_f32, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->grads,
+                               e->shard_segs(), step_tail_of(e, a.batch, 1));
         }
     } else if (op == OP_EVAL) {
         int rc = launch_forward(e, a);
         if (rc) return rc;
         if (a.use_cursor) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), a.batch, 1, 0);
     } else if (op == OP_ADAM) {
+        StepTail none;
+        memset(&none, 0, sizeof none);
+        // forward_backward already counted this optimiser step (its first kernel bumps adam_step)
         hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
-                           (const double*)nullptr, (const float*)e->grads, e->m, e->v, e->hp,
-                           (const StepState*)e->state(), e->shard_segs());
-        hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), 0, 0, 1);
+                           (const float*)e->grads, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(),
+                           none, 0);
     }
     HIP_TRY(hipGetLastError());
     return CAE_OK;
@@ -1032,6 +1069,8 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
 void cae_engine_destroy(cae_engine* e) {
     if (!e) return;
     e->drop_graphs();
+    for (auto ev : e->fork_events) (void)hipEventDestroy(ev);
+    if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
 }
 
@@ -1067,6 +1106,7 @@ int cae_set_stream(cae_engine* e, void* hip_stream) {
     if (!e) return fail(CAE_ERR_ARG, "null engine");
     if (e->stream != (hipStream_t)hip_stream) e->drop_graphs();
     e->stream = (hipStream_t)hip_stream;
+    if (e->stream && !e->side) HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
     return CAE_OK;
 }
 

@@ -42,19 +42,18 @@ struct GemmArgs {
 // One workgroup = 4 waves = one 16x16 tile of C; the waves split K into 4 contiguous chunks
 // (split-K inside the workgroup, combined through LDS), so even a 64x128x576 product keeps
 // every k-chain short.  Loads are issued 8 k-steps at a time ahead of their MFMAs.
-__global__ void __launch_bounds__(256) k_gemm16(GemmArgs g) {
-    extern __shared__ double lds_d[];
+__device__ __forceinline__ void gemm16_body(const GemmArgs& g, const int bx, double* lds_d) {
     float* part = reinterpret_cast<float*>(lds_d);              // [4 waves][256] partial tiles
     float* lstat = part + 4 * 256;                              // [<=64 channels][2] GE_BN_MASK sums
     float4* ca = reinterpret_cast<float4*>(lstat + 128);
     float4* cc = ca + (g.bn_a.mode ? g.bn_a.C : 0);
-    bn_consts(g.bn_a, ca, blockIdx.x == 0);
+    bn_consts(g.bn_a, ca, bx == 0);
     bn_consts(g.bn_c, cc, false);
     if (threadIdx.x < 128) lstat[threadIdx.x] = 0.f;
     __syncthreads();
 
     const int tiles_n = (g.N + 15) >> 4;
-    const int tile = blockIdx.x;
+    const int tile = bx;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
@@ -136,10 +135,23 @@ __global__ void __launch_bounds__(256) k_gemm16(GemmArgs g) {
         const int i = threadIdx.x;
         if (i < 2 * (c1 - c0 + 1)) {
             const int ch = c0 + (i >> 1);
-            atomicAdd(&g.stats_c[((size_t)(blockIdx.x & (kStatShards - 1)) * g.bn_c.C + ch) * 4 + 2 + (i & 1)],
+            atomicAdd(&g.stats_c[((size_t)(bx & (kStatShards - 1)) * g.bn_c.C + ch) * 4 + 2 + (i & 1)],
                       (double)lstat[2 * ch + (i & 1)]);
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_gemm16(GemmArgs g) {
+    extern __shared__ double lds_d[];
+    gemm16_body(g, blockIdx.x, lds_d);
+}
+
+// two independent GEMMs in one launch (a Linear layer's weight gradient beside its input gradient):
+// workgroups [0, na) run `a`, the rest run `b`
+__global__ void __launch_bounds__(256) k_gemm16_pair(GemmArgs a, GemmArgs b, int na) {
+    extern __shared__ double lds_d[];
+    if ((int)blockIdx.x < na) gemm16_body(a, blockIdx.x, lds_d);
+    else gemm16_body(b, blockIdx.x - na, lds_d);
 }
 
 }  // namespace cae

@@ -85,6 +85,7 @@ struct Src {
     const int* perm;   // dataset gather: sample = perm[batch_start + b]   (nullptr: sample = b)
     int use_cursor;    // add StepState.batch_start even when perm == nullptr
     int C, H, W;
+    int bump_adam;     // first kernel of a training step: its designated block starts optimiser step t+1
 };
 
 enum EpiKind : int { EPI_PLAIN = 0, EPI_STATS = 1, EPI_MASKSTATS = 2, EPI_SIGMSE = 3, EPI_SIGOUT = 4 };
@@ -295,6 +296,8 @@ __global__ void __launch_bounds__(256) k_down(ConvGeom g, Src big, BnDesc bnb, c
     const bool designated = blockIdx.x == 0 && blockIdx.y == 0;
     bn_consts(bnb, cb, designated);
     bn_consts(bne, ce, false);
+    // no kernel of the forward/backward pass reads adam_step, so bumping it here cannot race
+    if (designated && threadIdx.x == 0 && big.bump_adam) const_cast<StepState*>(st)->adam_step += 1;
     __syncthreads();
 
     const int cs = blockIdx.y;
@@ -556,36 +559,80 @@ struct Hyper {
     double lr, beta1, beta2, eps, wd;
 };
 
+// What the last kernel of a step does besides its own work: zero the accumulators for the next step
+// (each fp64 gradient slot is cleared by the thread that just consumed it; the BatchNorm sum tables,
+// which nobody reads any more, by a grid-stride sweep) and move the cursor (nobody in this kernel
+// reads batch_start / loss_slot).
+struct StepTail {
+    double* zero_extra;       // BatchNorm sum tables (and whatever else sits before the gradient accumulator)
+    long long zero_extra_n;   // doubles
+    double* acc_rw;           // fp64 gradient accumulator, writable view (or nullptr)
+    double* shard_rw;         // sharded side table, writable view (or nullptr)
+    StepState* st;
+    int batch_inc, slot_inc;
+};
+
+__device__ __forceinline__ float consume_grad(const StepTail& tl, const ShardSegs& ss, long long i) {
+    double g = tl.acc_rw[i];
+    tl.acc_rw[i] = 0.0;
+    for (int s = 0; s < ss.nseg; s++) {
+        const long long d = i - ss.seg[s].param_off;
+        if (d >= 0 && d < ss.seg[s].count) {
+            for (int sh = 0; sh < kStatShards; sh++) {
+                double* p = tl.shard_rw + (size_t)sh * ss.n + ss.seg[s].sh_off + d;
+                g += *p;
+                *p = 0.0;
+            }
+        }
+    }
+    return (float)g;
+}
+
+__device__ __forceinline__ void step_tail(const StepTail& tl, long long gid, long long nthreads) {
+    for (long long j = gid; j < tl.zero_extra_n; j += nthreads) tl.zero_extra[j] = 0.0;
+    if (gid == 0 && tl.st) {
+        tl.st->batch_start += tl.batch_inc;
+        tl.st->loss_slot += tl.slot_inc;
+    }
+}
+
 // torch.optim.Adam single-tensor update (L2 weight decay added to the gradient), element-wise
-// over the flat arena.  Gradient source: fp64 accumulator (fused path) or fp32 arena (DP path).
-__global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p, const double* __restrict__ acc,
-                                               const float* __restrict__ g32, float* __restrict__ m,
-                                               float* __restrict__ v, Hyper h, const StepState* __restrict__ st,
-                                               ShardSegs ss) {
+// over the flat arena.  Gradient source: fp64 accumulators (fused path; consumed and cleared) or
+// the fp32 arena (data-parallel path, after the all-reduce).  st->adam_step is the number of the
+// step being taken (bumped by the first kernel of the step / by cae_adam_step's own bump flag).
+__global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p, const float* __restrict__ g32,
+                                               float* __restrict__ m, float* __restrict__ v, Hyper h,
+                                               const StepState* __restrict__ st, ShardSegs ss, StepTail tl, int t_add) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tl.zero_extra || tl.st) step_tail(tl, i, (long long)gridDim.x * 256);
     if (i >= n) return;
-    const int t = st->adam_step + 1;
+    const int t = st->adam_step + t_add;
     const double bc1 = 1.0 - pow(h.beta1, (double)t);
     const double bc2 = 1.0 - pow(h.beta2, (double)t);
     const float step_size = (float)(h.lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     const float b1 = (float)h.beta1, b2 = (float)h.beta2;
-    float g = acc ? (float)(acc[i] + sharded_grad(ss, i)) : g32[i];
+    float g = g32 ? g32[i] : consume_grad(tl, ss, i);
     const float w = p[i];
     if (h.wd != 0.0) g = fmaf((float)h.wd, w, g);
     float mi = m[i], vi = v[i];
-    mi = mi + (g - mi) * (1.0f - b1);
-    vi = vi * b2 + ((1.0f - b2) * g) * g;
+    mi = mi + (g - mi) * (float)(1.0 - h.beta1);
+    vi = vi * b2 + ((float)(1.0 - h.beta2) * g) * g;
     const float denom = sqrtf(vi) / bc2_sqrt + (float)h.eps;
     p[i] = w - step_size * (mi / denom);
     m[i] = mi;
     v[i] = vi;
+    (void)b1;
 }
 
-__global__ void k_acc_to_f32(long long n, const double* __restrict__ acc, float* __restrict__ g, ShardSegs ss) {
+__global__ void k_acc_to_f32(long long n, float* __restrict__ g, ShardSegs ss, StepTail tl) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) g[i] = (float)(acc[i] + sharded_grad(ss, i));
+    step_tail(tl, i, (long long)gridDim.x * 256);
+    if (i < n) g[i] = consume_grad(tl, ss, i);
 }
+
+// the optimiser step counter for the data-parallel path, where Adam runs as its own op
+__global__ void k_bump_adam(StepState* st) { st->adam_step += 1; }
 
 __global__ void k_set_state(StepState* st, long long batch_start, int loss_slot, int set_cursor, int adam_step,
                             int set_adam) {

@@ -154,8 +154,7 @@ struct IgDgrad {
 };
 
 // grid (ceil(Mtiles / (4*tiles_per_wave)), ceil(Cin/16)), block 256; LDS: see host
-__global__ void __launch_bounds__(256) k_ig_dgrad(IgDgrad a) {
-    extern __shared__ double lds_d[];
+__device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, const int by, double* lds_d) {
     const int K = a.Cout * a.KH * a.KW;
     float* lstat = reinterpret_cast<float*>(lds_d);               // [16][2]
     float* part = lstat + 32;                                     // [4][256] split-K partial tiles
@@ -176,7 +175,7 @@ __global__ void __launch_bounds__(256) k_ig_dgrad(IgDgrad a) {
     const int r = lane & 15, q = lane >> 4;
     const int HW = a.H * a.W;
     const int M = a.B * HW;
-    const int ci = blockIdx.y * 16 + r;
+    const int ci = by * 16 + r;
     const bool b_ok = ci < a.Cin;
     const float* bp = a.w + (size_t)ci * K;
     const int khw = a.KH * a.KW;
@@ -187,7 +186,7 @@ __global__ void __launch_bounds__(256) k_ig_dgrad(IgDgrad a) {
     const int kper = (((K + 3) / 4 + KS - 1) / KS + 7) / 8 * 32;   // k per slice, multiple of 32 (8 MFMA steps)
     const int kbeg = kslot * kper, kend = min(K, kbeg + kper);
     for (int tt = 0; tt < a.tiles_per_wave; tt++) {
-        const int tile = (blockIdx.x * (4 / KS) + mslot) * a.tiles_per_wave + tt;
+        const int tile = (bx * (4 / KS) + mslot) * a.tiles_per_wave + tt;
         const bool tile_ok = tile * 16 < M;
         const int m = tile * 16 + r;
         const bool a_ok = tile_ok && m < M;
@@ -256,9 +255,9 @@ __global__ void __launch_bounds__(256) k_ig_dgrad(IgDgrad a) {
         }
         __syncthreads();
         if (threadIdx.x < 32) {
-            const int c = blockIdx.y * 16 + (threadIdx.x >> 1);
+            const int c = by * 16 + (threadIdx.x >> 1);
             if (c < a.Cin) {
-                const int shard = blockIdx.x & (kStatShards - 1);
+                const int shard = bx & (kStatShards - 1);
                 atomicAdd(&a.stats_prev[((size_t)shard * a.Cin + c) * 4 + 2 + (threadIdx.x & 1)], (double)lstat[threadIdx.x]);
             }
         }
@@ -279,14 +278,13 @@ struct IgWgrad {
 };
 
 // grid (Mtiles*Ntiles, K chunks), block 256: the 4 waves split the chunk, LDS combine, fp64 atomics
-__global__ void __launch_bounds__(256) k_ig_wgrad(IgWgrad a) {
-    extern __shared__ double lds_d[];
+__device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, const int by, double* lds_d) {
     float* part = reinterpret_cast<float*>(lds_d);            // [4][256]
     float4* cin4 = reinterpret_cast<float4*>(part + 1024);    // [Cin]
     float4* cout4 = cin4 + a.Cin;                             // [Cout]
     bn_consts(a.bn_in, cin4, false);
     bn_consts(a.bn_out, cout4, false);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && a.bg.stats) {
+    if (bx == 0 && by == 0 && a.bg.stats) {
         for (int c = threadIdx.x; c < a.bg.C; c += 256) {
             double sb = 0.0, sg = 0.0;
             for (int sh = 0; sh < kStatShards; sh++) {
@@ -304,7 +302,7 @@ __global__ void __launch_bounds__(256) k_ig_wgrad(IgWgrad a) {
     const int HW = a.H * a.W;
     const int K = a.B * HW;
     const int tiles_n = (N + 15) >> 4;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int tm = bx / tiles_n, tn = bx - tm * tiles_n;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
     const int ci = tm * 16 + r;                      // A row of this lane
@@ -318,7 +316,7 @@ __global__ void __launch_bounds__(256) k_ig_wgrad(IgWgrad a) {
     const float4 kb = (a.bn_out.mode == BN_BWD && b_ok) ? cout4[co] : make_float4(0, 0, 0, 0);
 
     const int steps = (K + 3) >> 2;
-    const int s_begin = blockIdx.y * a.ksteps_per_block;
+    const int s_begin = by * a.ksteps_per_block;
     const int s_end = min(steps, s_begin + a.ksteps_per_block);
     const int per = (s_end - s_begin + 3) >> 2;
     const int s0 = s_begin + wv * per, s1 = min(s_end, s0 + per);
@@ -361,6 +359,26 @@ __global__ void __launch_bounds__(256) k_ig_wgrad(IgWgrad a) {
         const float v = part[j * 64 + lane] + part[256 + j * 64 + lane] + part[512 + j * 64 + lane] + part[768 + j * 64 + lane];
         atomicAdd(&a.wacc[(size_t)cm * N + cn], (double)v);
     }
+}
+
+__global__ void __launch_bounds__(256) k_ig_dgrad(IgDgrad a) {
+    extern __shared__ double lds_d[];
+    ig_dgrad_body(a, blockIdx.x, blockIdx.y, lds_d);
+}
+
+__global__ void __launch_bounds__(256) k_ig_wgrad(IgWgrad a) {
+    extern __shared__ double lds_d[];
+    ig_wgrad_body(a, blockIdx.x, blockIdx.y, lds_d);
+}
+
+// weight gradient and input gradient of one layer in a single launch: workgroups [0, nw) are the
+// (tile, K-chunk) grid of the weight gradient, the rest the (M-tile, Cin-tile) grid of the input gradient
+__global__ void __launch_bounds__(256) k_ig_bwd_pair(IgWgrad w, IgDgrad d, int w_gx, int w_gy, int d_gx) {
+    extern __shared__ double lds_d[];
+    const int nw = w_gx * w_gy;
+    const int id = blockIdx.x;
+    if (id < nw) ig_wgrad_body(w, id % w_gx, id / w_gx, lds_d);
+    else ig_dgrad_body(d, (id - nw) % d_gx, (id - nw) / d_gx, lds_d);
 }
 
 }  // namespace cae
