@@ -302,6 +302,22 @@ template <int CIN, int COUT, int KH, int KW>
 void s2_fwd_launch(S2Fwd a, hipStream_t s) {
     // each thread covers 2x2 quads; lanes run along the row
     const int px = ((a.OW + 1) / 2 + 1) / 2, py = ((a.OH + 1) / 2 + 1) / 2;   // thread columns / rows per image
+    if ((long long)a.B * px * py < 100000) {
+        // small maps: 4x4 outputs per thread would leave most SIMDs without a wave; one quad per thread
+        const int qx = (a.OW + 1) / 2, qy = (a.OH + 1) / 2;
+        if (qx > 32) {
+            a.tiles_x = (qx + 63) / 64;
+            a.tiles_y = (qy + 3) / 4;
+            a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+            hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
+        } else {
+            a.tiles_x = (qx + 31) / 32;
+            a.tiles_y = (qy + 7) / 8;
+            a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+            hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
+        }
+        return;
+    }
     if (px > 32) {
         a.tiles_x = (px + 63) / 64;
         a.tiles_y = (py + 3) / 4;
@@ -722,17 +738,17 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 }
                 const int tiles_d = ((gd.M + 15) / 16) * ((gd.N + 15) / 16);
                 if (i == 0) {
-                    // the first encoder Linear's input carries BatchNorm+ReLU on the B side of the weight
-                    // gradient: the generic kernel handles that one (36 x fc_size values)
-                    {
-                        ProfScope _p(e, "linear_wgrad", i, f4((double)B * (F.nin + F.nout)) + 8.0 * F.nin * F.nout);
-                        hipLaunchKernelGGL(k_lin_wgrad, dim3(grid1((int64_t)F.nin * F.nout)), dim3(256),
-                                           lds_bytes(P.cout, 0), s, B, F.nin, F.nout, gout, in, bni, hw,
-                                           acc + F.w_off, acc + F.b_off);
-                    }
-                    ProfScope _p(e, "linear_dgrad_mfma", i, f4((double)B * (2.0 * F.nin + F.nout) + (double)F.nin * F.nout));
-                    hipLaunchKernelGGL(k_gemm16, dim3(tiles_d), dim3(256), lds, s, gd);
-                } else {
+                    // the first encoder Linear's input carries BatchNorm+ReLU: compute dW^T = act(in)^T * gout so
+                    // the transform sits on the A operand (channel = row / hw), store transposed; the ones ROW
+                    // of A yields the bias gradient
+                    gw.M = F.nin + 1; gw.N = F.nout; gw.K = B;
+                    gw.A = in; gw.sa_m = 1; gw.sa_k = F.nin;            // A[m=i][k=b] = in[b][i]
+                    gw.B = gout; gw.sb_k = F.nout; gw.sb_n = 1;         // B[k=b][n=o] = gout[b][o]
+                    gw.epi = GE_ACC64_T;
+                    gw.ones_col = 0; gw.ones_row = 1;
+                    gw.bn_a = bni; gw.hw_a = hw; gw.bn_a_by_row = 1;
+                }
+                {
                     const int tiles_w = ((gw.M + 15) / 16) * ((gw.N + 15) / 16);
                     ProfScope _p(e, "linear_bwd_pair_mfma", i,
                                  f4((double)B * (3.0 * F.nin + 2.0 * F.nout) + (double)F.nin * F.nout) + 8.0 * F.nin * F.nout);

@@ -18,7 +18,8 @@ enum GemmEpi : int {
     GE_STORE = 0,        // C = acc (+bias[n]) (relu)
     GE_RELU_MASK = 1,    // C = H[m][n] > 0 ? acc : 0        (gradient through the producer's ReLU)
     GE_BN_MASK = 2,      // C = bnrelu(Y[m][n]) > 0 ? acc : 0, D1/D2 sums of channel n / hw
-    GE_ACC64 = 3         // double accumulator: accW[m][n] = acc, column N-1 (ones) -> accB[m]
+    GE_ACC64 = 3,        // double accumulator: accW[m][n] = acc, column N-1 (ones) -> accB[m]
+    GE_ACC64_T = 4       // transposed: accW[n][m] = acc, row M-1 of A is the constant 1 -> accB[n]
 };
 
 struct GemmArgs {
@@ -32,11 +33,13 @@ struct GemmArgs {
     const float* H;        // GE_RELU_MASK / GE_BN_MASK: same indexing as C
     BnDesc bn_a;           // BatchNorm+ReLU applied to A elements, channel = k / hw_a (BN_NONE: identity)
     int hw_a;
+    int bn_a_by_row;       // 1: the BatchNorm channel of A[m][k] is m / hw_a (default: k / hw_a)
     BnDesc bn_c;           // GE_BN_MASK: BN_SAVED descriptor, channel = n / hw_c
     int hw_c;
     double* stats_c;       // GE_BN_MASK: [C][4] sums (slots 2,3)
     double* accW; double* accB;  // GE_ACC64; B's last column (n == N-1) is the constant 1 when ones_col
     int ones_col;
+    int ones_row;                // GE_ACC64_T: A's last row (m == M-1) is the constant 1
 };
 
 // One workgroup = 4 waves = one 16x16 tile of C; the waves split K into 4 contiguous chunks
@@ -61,6 +64,7 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g, const int bx, dou
     const int bn = tn * 16 + r;   // B column fetched by this lane
     const bool am_ok = am < g.M, bn_ok = bn < g.N;
     const bool b_ones = g.ones_col && bn == g.N - 1;
+    const bool a_ones = g.ones_row && am == g.M - 1;
     const float* ap = g.A + (long long)am * g.sa_m;
     const float* bp = g.B + (long long)bn * g.sb_n;
 
@@ -76,10 +80,11 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g, const int bx, dou
         for (int u = 0; u < 8; u++) {
             const int k = (st + u) * 4 + q;
             const bool k_ok = (st + u) < s1 && k < g.K;
-            a[u] = (am_ok && k_ok) ? ap[(long long)k * g.sa_k] : 0.f;
+            a[u] = (am_ok && k_ok) ? (a_ones ? 1.0f : ap[(long long)k * g.sa_k]) : 0.f;
             b[u] = (bn_ok && k_ok) ? (b_ones ? 1.0f : bp[(long long)k * g.sb_k]) : 0.f;
-            if (g.bn_a.mode != BN_NONE && am_ok && k_ok) {
-                const float4 c4 = ca[k / g.hw_a];
+            if (g.bn_a.mode != BN_NONE && am_ok && k_ok && !a_ones) {
+                // channel of an A element: k / hw_a, or m / hw_a when the transform runs along the rows
+                const float4 c4 = ca[(g.bn_a_by_row ? am : k) / g.hw_a];
                 a[u] = fmaxf(0.f, fmaf(a[u] - c4.x, c4.y, c4.z));
             }
         }
@@ -120,6 +125,12 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g, const int bx, dou
                 g.C[off] = gm;
                 atomicAdd(&lstat[2 * ch], gm);              // LDS atomics: a tile spans <= 16 channels
                 atomicAdd(&lstat[2 * ch + 1], gm * (d * c4.w));
+            } else if (g.epi == GE_ACC64_T) {
+                if (g.ones_row && cm == g.M - 1) {
+                    g.accB[cn] = (double)v;
+                } else {
+                    g.accW[(long long)cn * (g.M - (g.ones_row ? 1 : 0)) + cm] = (double)v;
+                }
             } else {  // GE_ACC64
                 if (g.ones_col && cn == g.N - 1) {
                     g.accB[cm] = (double)v;
