@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--table", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--launch-order", default=None, help="write the per-step launch sequence [label, algorithmic bytes] here")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -200,6 +201,10 @@ def main():
         recs = eng.profile_end()
         eng._read_losses(0, prof_steps)
         roof, table, step_us = roofline_from_profile(recs, prof_steps)
+        if args.launch_order:
+            per = len(recs) // prof_steps
+            with open(args.launch_order, "w") as f:
+                json.dump([[f"{n}[layer {l}]", b] for (n, l, _, b) in recs[:per]], f)
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
