@@ -26,6 +26,8 @@ class ProfileRecC(C.Structure):
                 ("bytes", C.c_double)]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+
 # name -> (restype, argtypes); every symbol include/cae_hip.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -50,6 +52,7 @@ SIGNATURES = {
     "cae_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "cae_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
     "cae_adam_step": (C.c_int, [_P]),
+    "cae_forward_backward_sync": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, ALLREDUCE_FN, _P]),
     "cae_eval_step": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "cae_score": (C.c_int, [_P, _P, C.c_int, _P]),
     "cae_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),

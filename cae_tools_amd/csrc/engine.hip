@@ -281,7 +281,20 @@ struct StepArgs {
     const float* x_direct; // score(): explicit input batch
     float* yhat;           // eval: sigmoid output destination (may be nullptr)
     bool want_loss;        // eval: accumulate MSE into the loss slot
+    // SyncBN (cae_forward_backward_sync): after every launch that completes a BatchNorm sum table the
+    // caller's function sums that table over the data-parallel ranks
+    cae_allreduce_fn sync_fn = nullptr;
+    void* sync_user = nullptr;
+    int world = 1;
 };
+
+int sync_bn_table(cae_engine* e, const StepArgs& a, int bn_index) {
+    if (!a.sync_fn) return CAE_OK;
+    const int64_t n = (int64_t)kStatShards * e->bn_channels[bn_index] * 4;
+    if (a.sync_fn(a.sync_user, e->bn_stats(bn_index), n) != 0)
+        return fail(CAE_ERR_STATE, "the all-reduce callback failed for BatchNorm table %d", bn_index);
+    return CAE_OK;
+}
 
 // ---- specialised stride-2 kernels (kernels_s2.h): dispatch on (Cin, Cout, kh, kw) ----------------
 
@@ -414,6 +427,8 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
         ProfScope _p(e, a.train ? "enc_conv_fwd" : "enc_conv_eval", (int)l, f4((double)B * (L.in_elems() + L.out_elems())));
         hipLaunchKernelGGL(k_down, grid, dim3(256), lds_bytes(L.cin, L.cout), s, g, big, bnb, e->params + L.w_off,
                            e->params + L.b_off, ep, bn_none(), st);
+        if (a.train)
+            if (int rc = sync_bn_table(e, a, L.bn_index)) return rc;
     }
     // ---- encoder_lin / decoder_lin (encoder.py:54-58, decoder.py:31-35)
     {
@@ -513,6 +528,8 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             ProfScope _p(e, last ? (a.train ? "s2_convt_last_fwd_loss" : "s2_convt_last_eval") : (a.train ? "s2_convt_fwd" : "s2_convt_eval"), (int)l,
                          f4((double)B * (L.in_elems() + L.out_elems() * (last && (a.train || a.want_loss) ? 2.0 : 1.0))));
             s2_fwd_dispatch(L, f, s);
+            if (a.train && !last)
+                if (int rc = sync_bn_table(e, a, L.bn_index)) return rc;
             continue;
         }
         if (e->use_s2 && !last && L.stride == 2 && L.kh <= 4 && L.kw <= 4) {
@@ -529,6 +546,8 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             dim3 grid((mtiles + per_block - 1) / per_block, 4, (L.cout + 15) / 16);
             ProfScope _p(e, a.train ? "ig_convt_fwd" : "ig_convt_eval", (int)l, f4((double)B * (L.in_elems() + L.out_elems())));
             hipLaunchKernelGGL(k_ig_fwd_s2, grid, dim3(256), (32 + 1024) * sizeof(float) + (size_t)(L.cin + 1) * sizeof(float4), s, f);
+            if (a.train)
+                if (int rc = sync_bn_table(e, a, L.bn_index)) return rc;
             continue;
         }
         dim3 grid(grid1((int64_t)B * L.hout * L.wout), L.cout);
@@ -536,6 +555,8 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
                      f4((double)B * (L.in_elems() + L.out_elems() * (last && (a.train || a.want_loss) ? 2.0 : 1.0))));
         hipLaunchKernelGGL(k_up, grid, dim3(256), lds_bytes(L.cin, L.cout), s, g, small, bns, e->params + L.w_off,
                            e->params + L.b_off, ep, bn_none(), st);
+        if (a.train && !last)
+            if (int rc = sync_bn_table(e, a, L.bn_index)) return rc;
     }
     return CAE_OK;
 }
@@ -598,11 +619,13 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 f.bg.gamma_acc = acc + L.gamma_off;
                 f.bg.beta_acc = acc + L.beta_off;
                 f.bg.C = L.cout;
-                f.bg.scale = 1.0;
+                f.bg.scale = 1.0 / a.world;
             }
             ProfScope _p(e, "s2_convt_bwd", l,
                          f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * 2.0)));
             s2_bwd_dispatch(L, f, s);
+            if (l > 0)
+                if (int rc = sync_bn_table(e, a, e->dec[l - 1].bn_index)) return rc;
             continue;
         }
         if (e->use_s2) {
@@ -617,7 +640,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 fw.bg.gamma_acc = acc + L.gamma_off;
                 fw.bg.beta_acc = acc + L.beta_off;
                 fw.bg.C = L.cout;
-                fw.bg.scale = 1.0;
+                fw.bg.scale = 1.0 / a.world;
             }
             const int wtiles = ((L.cin + 15) / 16) * ((L.cout * L.kh * L.kw + 15) / 16);
             const int steps = (B * L.hin * L.win + 3) / 4;
@@ -655,6 +678,8 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                          f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));
             hipLaunchKernelGGL(k_ig_bwd_pair, dim3(wtiles * chunks + d_gx * d_gy), dim3(256), lds_d > lds_w ? lds_d : lds_w, s,
                                fw, fd, wtiles, chunks, d_gx);
+            if (l > 0)
+                if (int rc = sync_bn_table(e, a, e->dec[l - 1].bn_index)) return rc;
             continue;
         }
         // weight gradient (+ BN parameter gradients of this layer)
@@ -669,7 +694,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 bg.gamma_acc = acc + L.gamma_off;
                 bg.beta_acc = acc + L.beta_off;
                 bg.C = L.cout;
-                bg.scale = 1.0;
+                bg.scale = 1.0 / a.world;
             }
             dim3 grid((unsigned)nw, (unsigned)((pos + ppb - 1) / ppb));
             ProfScope _p(e, "dec_convt_wgrad", l, f4((double)B * (L.in_elems() + L.out_elems() * (last ? 1.0 : 2.0))));
@@ -695,6 +720,8 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             ProfScope _p(e, "dec_convt_dgrad", l, f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));
             hipLaunchKernelGGL(k_down, grid, dim3(256), lds_bytes(L.cout, L.cin), s, g, gy, bng, e->params + L.w_off,
                                (const float*)nullptr, ep, bne, st);
+            if (l > 0)
+                if (int rc = sync_bn_table(e, a, e->dec[l - 1].bn_index)) return rc;
         }
     }
     // ---- Linear layers, last first.  grad_off of fc[i] holds dL/d(pre-activation of fc[i] output).
@@ -754,6 +781,8 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                                  f4((double)B * (3.0 * F.nin + 2.0 * F.nout) + (double)F.nin * F.nout) + 8.0 * F.nin * F.nout);
                     hipLaunchKernelGGL(k_gemm16_pair, dim3(tiles_w + tiles_d), dim3(256), lds, s, gw, gd, tiles_w);
                 }
+                if (i == 0)
+                    if (int rc = sync_bn_table(e, a, P.bn_index)) return rc;
                 continue;
             }
             {
@@ -774,6 +803,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 hipLaunchKernelGGL(k_lin_dgrad, grid, dim3(256), lds_bytes(P.cout, 0), s, B, F.nin, F.nout, gout,
                                    e->params + F.w_off, 2, e->fptr(P.act_off), bni, hw, e->bn_stats(P.bn_index),
                                    e->fptr(P.grad_off));
+                if (int rc = sync_bn_table(e, a, P.bn_index)) return rc;
             }
         }
     }
@@ -805,7 +835,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             bg.gamma_acc = acc + L.gamma_off;
             bg.beta_acc = acc + L.beta_off;
             bg.C = L.cout;
-            bg.scale = 1.0;
+            bg.scale = 1.0 / a.world;
             dim3 grid((unsigned)nw, (unsigned)((pos + ppb - 1) / ppb));
             if (int rc = stream_after(e, s, ws)) return rc;
             ProfScope _p(e, "enc_conv_wgrad", l, f4((double)B * (L.in_elems() + 2.0 * L.out_elems())), ws);
@@ -824,6 +854,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             ProfScope _p(e, "enc_conv_dgrad", l, f4((double)B * (2.0 * L.out_elems() + 2.0 * L.in_elems())));
             hipLaunchKernelGGL(k_up, grid, dim3(256), lds_bytes(L.cout, L.cin), s, g, gy, bng, e->params + L.w_off,
                                (const float*)nullptr, ep, bne, st);
+            if (int rc = sync_bn_table(e, a, P.bn_index)) return rc;
         }
     }
     if (int rc = stream_after(e, ws, s)) return rc;   // join: Adam needs every weight gradient
@@ -1185,6 +1216,18 @@ int cae_forward_backward(cae_engine* e, int which, const int32_t* perm, int batc
     if (global_batch < batch) return fail(CAE_ERR_ARG, "global_batch < batch");
     StepArgs a{which, perm, batch, global_batch, batch, true, true, nullptr, nullptr, true};
     return run_op(e, OP_FWDBWD, a, true);
+}
+
+int cae_forward_backward_sync(cae_engine* e, int which, const int32_t* perm, int batch, int global_batch, int world,
+                              cae_allreduce_fn fn, void* user) {
+    int rc = check_ready(e, which, batch, true);
+    if (rc) return rc;
+    if (global_batch < batch || world < 1 || !fn) return fail(CAE_ERR_ARG, "cae_forward_backward_sync: bad argument");
+    StepArgs a{which, perm, batch, global_batch, global_batch, true, true, nullptr, nullptr, true};
+    a.sync_fn = fn;
+    a.sync_user = user;
+    a.world = world;
+    return run_op(e, OP_FWDBWD, a, false);   // plain launches: the callback runs between them
 }
 
 int cae_adam_step(cae_engine* e) {

@@ -6,7 +6,9 @@ the global batch of a step is the union of the ranks' local batches; the loss is
 global batch, so each rank back-propagates sum(local terms)/global_count and the SUM all-reduce
 yields the global-mean gradient on every rank; Adam then runs identically everywhere (weights stay
 bit-identical across ranks because they start equal and see the same reduced gradient).
-BatchNorm uses per-rank batch statistics (torch DDP's default behaviour without SyncBatchNorm).
+BatchNorm uses per-rank batch statistics by default (torch DDP's behaviour without SyncBatchNorm);
+sync_bn=True all-reduces the BatchNorm sum tables between launches so that N ranks x batch/N give
+the single-device batch-N result.
 
 `engine` is anything with: .grads (flat tensor), .forward_backward(which, perm, start, size,
 global_batch) and .adam_step() — HipEngine in production; the gloo CPU tests drive the same class
@@ -19,10 +21,11 @@ import torch
 
 class DataParallel:
 
-    def __init__(self, engine, dist, group=None):
+    def __init__(self, engine, dist, group=None, sync_bn=False):
         self.engine = engine
         self.dist = dist
         self.group = group
+        self.sync_bn = sync_bn   # BatchNorm over the global batch (parity with the single-device reference)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._sizes = None
@@ -49,7 +52,12 @@ class DataParallel:
     def train_step(self, which, perm, start, size, global_batch=None):
         """one optimiser step on this rank's shard perm[start:start+size]"""
         gb = global_batch if global_batch is not None else size * self.world
-        slot = self.engine.forward_backward(which, perm, start, size, gb)
+        if self.sync_bn:
+            slot = self.engine.forward_backward_sync(
+                which, perm, start, size, gb, self.world,
+                lambda table: self.dist.all_reduce(table, op=self.dist.ReduceOp.SUM, group=self.group))
+        else:
+            slot = self.engine.forward_backward(which, perm, start, size, gb)
         with self._stream_ctx():
             self.dist.all_reduce(self.engine.grads, op=self.dist.ReduceOp.SUM, group=self.group)
         self.engine.adam_step()

@@ -283,6 +283,36 @@ class HipEngine(EnginePlan):
         self.num_batches_tracked += 1
         return first
 
+    def forward_backward_sync(self, which, perm_dev, start, size, global_batch, world, allreduce):
+        """forward_backward with BatchNorm over the global batch: `allreduce(t)` is called with a float64
+        CUDA view of each BatchNorm sum table and must sum it over the ranks in place, enqueued on
+        self.stream (it is called inside `with torch.cuda.stream(self.stream)`)."""
+        first = self._claim_slots(1)
+        check(self.lib.cae_set_cursor(self.handle, int(start), first))
+        base = (self.workspace.data_ptr() + 255) // 256 * 256
+        pad = base - self.workspace.data_ptr()
+        failure = []
+
+        def _cb(user, table_ptr, count):
+            try:
+                off = pad + (table_ptr - base)
+                view = self.workspace[off:off + 8 * count].view(torch.float64)
+                with torch.cuda.stream(self.stream):
+                    allreduce(view)
+                return 0
+            except Exception as ex:  # surfaces after the C call returns
+                failure.append(ex)
+                return 1
+
+        cb = _lib.ALLREDUCE_FN(_cb)
+        rc = self.lib.cae_forward_backward_sync(self.handle, which, perm_dev.data_ptr() if perm_dev is not None else None,
+                                                int(size), int(global_batch), int(world), cb, None)
+        if failure:
+            raise failure[0]
+        check(rc)
+        self.num_batches_tracked += 1
+        return first
+
     def adam_step(self):
         check(self.lib.cae_adam_step(self.handle))
         self.adam_steps += 1

@@ -127,6 +127,17 @@ int cae_train_step(cae_engine* e, int which, const int32_t* perm_dev, int batch)
 int cae_forward_backward(cae_engine* e, int which, const int32_t* perm_dev, int batch, int global_batch);
 int cae_adam_step(cae_engine* e);
 
+/* The same half-step with BatchNorm statistics over the GLOBAL batch (SyncBN): the reference
+ * normalises over the whole batch on one device (encoder.py:45, decoder.py:47), so this is the mode
+ * in which N ranks x batch/N reproduce its batch-N result.  After every launch that completes a
+ * BatchNorm sum table ([8 shards][C][4] fp64: sum y, sum y^2 forward; sum g, sum g*xhat backward)
+ * the library calls fn(user, table_dev, count): it must leave in the table the element-wise SUM over
+ * all ranks, ordered on the engine's stream (e.g. an RCCL all-reduce enqueued on that stream), and
+ * return 0.  Plain launches, 2 calls per BatchNorm layer per step. */
+typedef int (*cae_allreduce_fn)(void* user, void* table_dev, int64_t count_doubles);
+int cae_forward_backward_sync(cae_engine* e, int which, const int32_t* perm_dev, int batch, int global_batch,
+                              int world, cae_allreduce_fn fn, void* user);
+
 /* One iteration of __test_epoch (conv_ae_model.py:205-221): eval-mode forward + MSE into the
  * loss slot; nothing else is written. */
 int cae_eval_step(cae_engine* e, int which, const int32_t* perm_dev, int batch);
