@@ -108,12 +108,18 @@ def roofline_from_profile(recs, steps):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL does under
+    # NCCL_DEBUG=VERSION) are diverted to stderr for the whole run
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--table", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--force-dp", action="store_true", help="use the data-parallel code path even with one rank (rehearsal)")
+    ap.add_argument("--sync-bn", action="store_true", help="data-parallel runs: BatchNorm over the global batch")
     ap.add_argument("--launch-order", default=None, help="write the per-step launch sequence [label, algorithmic bytes] here")
     args = ap.parse_args()
 
@@ -127,8 +133,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
@@ -141,7 +150,7 @@ def main():
     perm = eng.upload_perm(np.random.default_rng(99 + rank).permutation(N_TRAIN))
     steps_per_epoch = N_TRAIN // BATCH
 
-    if world == 1:
+    if dist is None:
         def run(nsteps):
             done = 0
             while done < nsteps:
@@ -150,7 +159,8 @@ def main():
                 done += n
     else:
         from cae_tools_amd.dp import DataParallel
-        dp = DataParallel(eng, dist)
+        dp = DataParallel(eng, dist, sync_bn=args.sync_bn)
+        dp.broadcast_parameters(0)
 
         def run(nsteps):
             for s in range(nsteps):
@@ -188,7 +198,7 @@ def main():
             "config": {"workload": "cfg2: ConvAEModel 'conv' 16x16->256x256 1-ch, fc128/latent32, batch 64 per GPU, "
                                    "train step = fwd+MSE+bwd+Adam, BatchNorm batch stats per GPU",
                        "global_batch": BATCH * world, "n_train": N_TRAIN, "params": 112271,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
+                       "parallelism": (f"dp{world}" + ("+syncbn" if args.sync_bn else "")) if dist is not None else "single"},
             "step_roofline": {"algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE,
                               "achieved_GBs": value / world * ALGO_BYTES_PER_IMAGE / 1e9,
                               "frac_of_8TBs": value / world * ALGO_BYTES_PER_IMAGE / 1e9 / HBM_PEAK_GBS},
@@ -219,7 +229,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(spec, enc, dec)
     barrier()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
