@@ -50,6 +50,8 @@ SIGNATURES = {
     "cae_set_cursor": (C.c_int, [_P, C.c_int64, C.c_int]),
     "cae_set_adam_step": (C.c_int, [_P, C.c_int]),
     "cae_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "cae_train_steps": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
+    "cae_eval_steps": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
     "cae_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
     "cae_adam_step": (C.c_int, [_P]),
     "cae_forward_backward_sync": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, ALLREDUCE_FN, _P]),
@@ -60,6 +62,7 @@ SIGNATURES = {
     "cae_sync": (C.c_int, [_P]),
     "cae_debug_read": (C.c_int64, [_P, C.c_char_p, C.c_int, _P, C.c_int64]),
     "cae_profile_begin": (C.c_int, [_P]),
+    "cae_debug_launch_floor": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "cae_profile_end": (C.c_int, [_P, C.POINTER(ProfileRecC), C.c_int]),
     "cae_scan_f32": (C.c_int, [_P, C.c_int64, _P, C.POINTER(C.c_double)]),
     "cae_normalise_pack": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_float,

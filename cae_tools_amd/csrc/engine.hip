@@ -106,7 +106,7 @@ struct cae_engine {
     struct ProfRec { const char* name; int layer; double bytes; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof;
     // key: (op, which, batch, global_batch, perm)
-    std::map<std::tuple<int, int, int, int, const void*>, hipGraphExec_t> graphs;
+    std::map<std::tuple<int, int, int, int, const void*, int>, hipGraphExec_t> graphs;
 
     StepState* state() const { return reinterpret_cast<StepState*>(ws + off_state); }
     double* losses() const { return reinterpret_cast<double*>(ws + off_losses); }
@@ -286,6 +286,7 @@ struct StepArgs {
     cae_allreduce_fn sync_fn = nullptr;
     void* sync_user = nullptr;
     int world = 1;
+    int nsteps = 1;        // consecutive steps of the same batch size in one captured graph
 };
 
 int sync_bn_table(cae_engine* e, const StepArgs& a, int bn_index) {
@@ -861,7 +862,17 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
     return CAE_OK;
 }
 
+int launch_one(cae_engine* e, int op, const StepArgs& a);
+
 int launch_op(cae_engine* e, int op, const StepArgs& a) {
+    // the cursor lives on the device, so the same launch sequence repeated n times walks n batches:
+    // n steps become one graph and the ~8.5 us the GPU idles between two graph replays is paid once
+    for (int i = 0; i < a.nsteps; i++)
+        if (int rc = launch_one(e, op, a)) return rc;
+    return CAE_OK;
+}
+
+int launch_one(cae_engine* e, int op, const StepArgs& a) {
     hipStream_t s = e->stream;
     e->fork_used = 0;
     if (op == OP_TRAIN || op == OP_FWDBWD) {
@@ -900,7 +911,7 @@ int launch_op(cae_engine* e, int op, const StepArgs& a) {
 int run_op(cae_engine* e, int op, const StepArgs& a, bool cacheable) {
     // the legacy NULL stream cannot be captured: plain launches there
     if (!e->graph_mode || !cacheable || e->stream == nullptr || e->profiling) return launch_op(e, op, a);
-    auto key = std::make_tuple(op, a.which, a.batch, a.global_batch, (const void*)a.perm);
+    auto key = std::make_tuple(op, a.which, a.batch, a.global_batch, (const void*)a.perm, a.nsteps);
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -1210,6 +1221,24 @@ int cae_train_step(cae_engine* e, int which, const int32_t* perm, int batch) {
     return run_op(e, OP_TRAIN, a, true);
 }
 
+int cae_train_steps(cae_engine* e, int which, const int32_t* perm, int batch, int nsteps) {
+    int rc = check_ready(e, which, batch, true);
+    if (rc) return rc;
+    if (nsteps < 1 || nsteps > 4096) return fail(CAE_ERR_ARG, "nsteps %d outside [1, 4096]", nsteps);
+    StepArgs a{which, perm, batch, batch, batch, true, true, nullptr, nullptr, true};
+    a.nsteps = nsteps;
+    return run_op(e, OP_TRAIN, a, true);
+}
+
+int cae_eval_steps(cae_engine* e, int which, const int32_t* perm, int batch, int nsteps) {
+    int rc = check_ready(e, which, batch, true);
+    if (rc) return rc;
+    if (nsteps < 1 || nsteps > 4096) return fail(CAE_ERR_ARG, "nsteps %d outside [1, 4096]", nsteps);
+    StepArgs a{which, perm, batch, batch, batch, false, true, nullptr, nullptr, true};
+    a.nsteps = nsteps;
+    return run_op(e, OP_EVAL, a, true);
+}
+
 int cae_forward_backward(cae_engine* e, int which, const int32_t* perm, int batch, int global_batch) {
     int rc = check_ready(e, which, batch, true);
     if (rc) return rc;
@@ -1322,6 +1351,34 @@ int64_t cae_debug_read(cae_engine* e, const char* what, int index, void* host_ou
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(host_out, src, (size_t)(n * esz), hipMemcpyDeviceToHost));
     return n;
+}
+
+// Measurement aid: per-node cost of a captured graph of n dependent no-op kernels on the engine's stream.
+int cae_debug_launch_floor(cae_engine* e, int n, double* micros_per_kernel) {
+    if (!e || !e->ws || !e->stream || n < 1 || !micros_per_kernel) return fail(CAE_ERR_ARG, "cae_debug_launch_floor: bad argument");
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < n; i++) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, e->stream, e->state(), 0, 0, 0);
+    HIP_TRY(hipStreamEndCapture(e->stream, &graph));
+    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) HIP_TRY(hipGraphLaunch(exec, e->stream));
+    HIP_TRY(hipEventRecord(e0, e->stream));
+    const int reps = 10;
+    for (int i = 0; i < reps; i++) HIP_TRY(hipGraphLaunch(exec, e->stream));
+    HIP_TRY(hipEventRecord(e1, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *micros_per_kernel = (double)ms * 1000.0 / (reps * (double)n);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    return CAE_OK;
 }
 
 int cae_profile_begin(cae_engine* e) {

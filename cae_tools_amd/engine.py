@@ -243,14 +243,27 @@ class HipEngine(EnginePlan):
         first = self._claim_slots(nb)
         ptr = perm_dev.data_ptr() if perm_dev is not None else None
         check(self.lib.cae_set_cursor(self.handle, 0, first))
-        fn = self.lib.cae_train_step if train else self.lib.cae_eval_step
-        for b in range(nb):
-            size = min(batch_size, n - b * batch_size)
-            check(fn(self.handle, which, ptr, size))
+        self._enqueue(which, ptr, n, batch_size, train)
         if train:
             self.num_batches_tracked += nb
             self.adam_steps += nb
         return self._read_losses(first, nb)
+
+    STEPS_PER_GRAPH = 64
+
+    def _enqueue(self, which, ptr, n, batch_size, train):
+        """one pass over n samples: the full batches in multi-step graphs, then the partial last batch"""
+        many = self.lib.cae_train_steps if train else self.lib.cae_eval_steps
+        one = self.lib.cae_train_step if train else self.lib.cae_eval_step
+        full = n // batch_size
+        # only two graph shapes per batch size (K steps, 1 step), so nothing is captured mid-run
+        while full >= self.STEPS_PER_GRAPH:
+            check(many(self.handle, which, ptr, batch_size, self.STEPS_PER_GRAPH))
+            full -= self.STEPS_PER_GRAPH
+        for _ in range(full):
+            check(one(self.handle, which, ptr, batch_size))
+        if n % batch_size:
+            check(one(self.handle, which, ptr, n % batch_size))
 
     def train_step(self, which, perm_dev, start, size):
         """a single training step on perm[start:start+size]; returns its loss (blocking)"""
@@ -267,8 +280,7 @@ class HipEngine(EnginePlan):
         nb = (n + batch_size - 1) // batch_size
         ptr = perm_dev.data_ptr() if perm_dev is not None else None
         check(self.lib.cae_set_cursor(self.handle, 0, slot_first))
-        for b in range(nb):
-            check(self.lib.cae_train_step(self.handle, which, ptr, min(batch_size, n - b * batch_size)))
+        self._enqueue(which, ptr, n, batch_size, True)
         self.num_batches_tracked += nb
         self.adam_steps += nb
         return nb

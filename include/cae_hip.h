@@ -121,6 +121,12 @@ int cae_set_adam_step(cae_engine* e, int completed_steps);
  * indices into dataset `which` (NULL = identity). */
 int cae_train_step(cae_engine* e, int which, const int32_t* perm_dev, int batch);
 
+/* nsteps consecutive training / test steps of the same batch size (the cursor walks the permutation):
+ * the inner loop of __train_epoch / __test_epoch over the full batches as ONE captured graph, so the
+ * idle time between two graph replays is paid once per call instead of once per step. */
+int cae_train_steps(cae_engine* e, int which, const int32_t* perm_dev, int batch, int nsteps);
+int cae_eval_steps(cae_engine* e, int which, const int32_t* perm_dev, int batch, int nsteps);
+
 /* Data-parallel split of the same step: forward+backward leaves the fp32 gradient of
  * sum(loss terms)/global_count in grads_dev (to be all-reduced by the caller), then
  * cae_adam_step applies Adam from grads_dev.  global_batch = batch summed over ranks. */
@@ -173,6 +179,8 @@ typedef struct {
     double bytes;
 } cae_profile_rec;
 int cae_profile_begin(cae_engine* e);
+/* measurement aid: cost per node of a captured graph of n dependent no-op kernels (blocking) */
+int cae_debug_launch_floor(cae_engine* e, int n, double* micros_per_kernel);
 int cae_profile_end(cae_engine* e, cae_profile_rec* out, int capacity);
 
 /* ---- loader kernels (stateless) ---------------------------------------------------------- */
