@@ -91,10 +91,6 @@ struct cae_engine {
     float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr, *bufs = nullptr;
     char* ws = nullptr;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;            // weight-gradient kernels run here, beside the dgrad chain
-    std::vector<hipEvent_t> fork_events;   // one per fork/join point of a step
-    size_t fork_used = 0;
-    bool use_side = false;  // measured: 397 vs 363 us/step - cross-queue fork/join costs more than it overlaps
     Hyper hp{1e-3, 0.9, 0.999, 1e-8, 1e-5};
     const float* ds_x[2] = {nullptr, nullptr};
     const float* ds_t[2] = {nullptr, nullptr};
@@ -252,20 +248,6 @@ struct ProfScope {
     }
 };
 
-// order `to` after everything enqueued so far on `from` (works eagerly and inside stream capture,
-// where it is what pulls the side stream into the captured graph)
-int stream_after(cae_engine* e, hipStream_t from, hipStream_t to) {
-    if (from == to) return CAE_OK;
-    if (e->fork_used == e->fork_events.size()) {
-        hipEvent_t ev;
-        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        e->fork_events.push_back(ev);
-    }
-    hipEvent_t ev = e->fork_events[e->fork_used++];
-    HIP_TRY(hipEventRecord(ev, from));
-    HIP_TRY(hipStreamWaitEvent(to, ev, 0));
-    return CAE_OK;
-}
 inline double f4(double n) { return 4.0 * n; }
 
 // ---- the step, as a sequence of launches on e->stream -------------------------------------------
@@ -564,9 +546,6 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
 
 int launch_backward(cae_engine* e, const StepArgs& a) {
     hipStream_t s = e->stream;
-    // weight gradients only feed Adam: they run on the side stream, concurrently with the chain of
-    // input-gradient kernels; every section first orders the side stream after the producer of gy
-    hipStream_t ws = (e->use_side && e->side && e->stream) ? e->side : e->stream;
     const int B = a.batch;
     const StepState* st = e->state();
     double* acc = e->gradacc();
@@ -838,9 +817,8 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             bg.C = L.cout;
             bg.scale = 1.0 / a.world;
             dim3 grid((unsigned)nw, (unsigned)((pos + ppb - 1) / ppb));
-            if (int rc = stream_after(e, s, ws)) return rc;
-            ProfScope _p(e, "enc_conv_wgrad", l, f4((double)B * (L.in_elems() + 2.0 * L.out_elems())), ws);
-            hipLaunchKernelGGL(k_wgrad, grid, dim3(256), lds_bytes(L.cout, L.cin), ws, g, gy, bng, ain, bna,
+            ProfScope _p(e, "enc_conv_wgrad", l, f4((double)B * (L.in_elems() + 2.0 * L.out_elems())), s);
+            hipLaunchKernelGGL(k_wgrad, grid, dim3(256), lds_bytes(L.cout, L.cin), s, g, gy, bng, ain, bna,
                                acc + L.w_off, ppb, bg, st);
         }
         if (l > 0) {
@@ -858,7 +836,6 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             if (int rc = sync_bn_table(e, a, P.bn_index)) return rc;
         }
     }
-    if (int rc = stream_after(e, ws, s)) return rc;   // join: Adam needs every weight gradient
     return CAE_OK;
 }
 
@@ -874,7 +851,6 @@ int launch_op(cae_engine* e, int op, const StepArgs& a) {
 
 int launch_one(cae_engine* e, int op, const StepArgs& a) {
     hipStream_t s = e->stream;
-    e->fork_used = 0;
     if (op == OP_TRAIN || op == OP_FWDBWD) {
         // the accumulators were zeroed by the previous step's last kernel (k_adam / k_acc_to_f32) or by
         // the caller's zero-filled workspace on the very first step
@@ -1127,8 +1103,6 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
 void cae_engine_destroy(cae_engine* e) {
     if (!e) return;
     e->drop_graphs();
-    for (auto ev : e->fork_events) (void)hipEventDestroy(ev);
-    if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
 }
 
@@ -1164,7 +1138,6 @@ int cae_set_stream(cae_engine* e, void* hip_stream) {
     if (!e) return fail(CAE_ERR_ARG, "null engine");
     if (e->stream != (hipStream_t)hip_stream) e->drop_graphs();
     e->stream = (hipStream_t)hip_stream;
-    if (e->stream && !e->side) HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
     return CAE_OK;
 }
 
