@@ -183,7 +183,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
 
     const int KS = a.ksplit;
     const int mslot = wv / KS, kslot = wv - mslot * KS;
-    const int kper = (((K + 3) / 4 + KS - 1) / KS + 7) / 8 * 32;   // k per slice, multiple of 32 (8 MFMA steps)
+    const int kper = (((K + 3) / 4 + KS - 1) / KS + 11) / 12 * 48;  // k per slice, multiple of 48 (12 MFMA steps)
     const int kbeg = kslot * kper, kend = min(K, kbeg + kper);
     for (int tt = 0; tt < a.tiles_per_wave; tt++) {
         const int tile = (bx * (4 / KS) + mslot) * a.tiles_per_wave + tt;
@@ -195,10 +195,10 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
         const size_t abase = (size_t)b * a.Cout * a.OH * a.OW + (size_t)(a.S * y) * a.OW + a.S * x;
 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = kbeg; k0 < kend; k0 += 32) {
-            float av[8], bv[8];
+        for (int k0 = kbeg; k0 < kend; k0 += 48) {
+            float av[12], bv[12];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 12; u++) {
                 const int k = k0 + 4 * u + q;
                 const bool k_ok = k < kend;
                 float v = 0.f;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
                 bv[u] = (b_ok && k_ok) ? bp[k] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < 12; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
         }
         if (KS > 1) {
             __syncthreads();
