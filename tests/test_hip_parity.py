@@ -255,3 +255,34 @@ def test_loader_kernels_bit_exact():
     y32 = npz["denorm_in"].astype(np.float32)
     got = denormalise_f64(torch.from_numpy(y32).cuda(), omin, omax).cpu().numpy()
     np.testing.assert_array_equal(got, omin + (y32.astype(np.float64) * (omax - omin)))
+
+
+def test_multi_step_graph_equals_single_steps():
+    """cae_train_steps / cae_eval_steps (64 steps per captured graph) walk the cursor exactly like 64
+    single-step launches: same per-batch losses, same weights afterwards."""
+    from cae_tools_amd.engine import HipEngine
+    case = GoldenCase("handspec_b4")
+    rng = np.random.default_rng(5)
+    n, bs = 2 * 66 + 1, 2                     # 66 full batches (one 64-step graph + 2 singles) + a partial one
+    (ic, ih, iw) = case.spec["input_layers"][0]["input_dimensions"]
+    (oc, oh, ow) = case.spec["output_layers"][-1]["output_dimensions"]
+    x = torch.from_numpy(rng.random((n, ic, ih, iw), dtype=np.float32)).cuda()
+    t = torch.from_numpy(rng.random((n, oc, oh, ow), dtype=np.float32)).cuda()
+    perm = rng.permutation(n)
+    results = []
+    for steps_per_graph in (64, 10 ** 9):
+        eng = _engine(case, max_batch=bs)
+        eng.STEPS_PER_GRAPH = steps_per_graph
+        eng.set_dataset(0, x, t)
+        pd = eng.upload_perm(perm)
+        tr = eng.run_batches(0, pd, n, bs, train=True)
+        ev = eng.run_batches(0, pd, n, bs, train=False)
+        eng.sync()
+        results.append((np.array(tr), np.array(ev), eng.params.cpu().numpy().copy(), eng.buffers.cpu().numpy().copy()))
+        assert len(tr) == 67 and eng.num_batches_tracked == 67
+    (a, b) = results
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-6)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-6)
+    # 67 Adam steps apart the two runs differ only by the arrival order of the fp64 atomics
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-5, atol=5e-6)
