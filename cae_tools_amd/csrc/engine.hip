@@ -296,6 +296,9 @@ bool s2_eligible(const cae_engine* e, const ConvLayer& L) { return e->use_s2 && 
 
 template <int CIN, int COUT, int KH, int KW>
 void s2_fwd_launch(S2Fwd a, hipStream_t s) {
+    // grid caps measured on MI355X at batch 64 (workgroups walk the remaining tiles): more workgroups
+    // only add fp64-atomic traffic at the end of the kernel
+    const int capf = 1024, capf2 = 512;
     // each thread covers 2x2 quads; lanes run along the row
     const int px = ((a.OW + 1) / 2 + 1) / 2, py = ((a.OH + 1) / 2 + 1) / 2;   // thread columns / rows per image
     if ((long long)a.B * px * py < 100000) {
@@ -305,12 +308,12 @@ void s2_fwd_launch(S2Fwd a, hipStream_t s) {
             a.tiles_x = (qx + 63) / 64;
             a.tiles_y = (qy + 3) / 4;
             a.total_tiles = a.B * a.tiles_x * a.tiles_y;
-            hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < capf ? a.total_tiles : capf), dim3(256), 0, s, a);
         } else {
             a.tiles_x = (qx + 31) / 32;
             a.tiles_y = (qy + 7) / 8;
             a.total_tiles = a.B * a.tiles_x * a.tiles_y;
-            hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_s2_fwd<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < capf ? a.total_tiles : capf), dim3(256), 0, s, a);
         }
         return;
     }
@@ -318,17 +321,17 @@ void s2_fwd_launch(S2Fwd a, hipStream_t s) {
         a.tiles_x = (px + 63) / 64;
         a.tiles_y = (py + 3) / 4;
         a.total_tiles = a.B * a.tiles_x * a.tiles_y;
-        hipLaunchKernelGGL((k_s2_fwd2<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_s2_fwd2<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < capf2 ? a.total_tiles : capf2), dim3(256), 0, s, a);
     } else if (px > 16) {
         a.tiles_x = (px + 31) / 32;
         a.tiles_y = (py + 7) / 8;
         a.total_tiles = a.B * a.tiles_x * a.tiles_y;
-        hipLaunchKernelGGL((k_s2_fwd2<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_s2_fwd2<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < capf2 ? a.total_tiles : capf2), dim3(256), 0, s, a);
     } else {
         a.tiles_x = (px + 15) / 16;
         a.tiles_y = (py + 15) / 16;
         a.total_tiles = a.B * a.tiles_x * a.tiles_y;
-        hipLaunchKernelGGL((k_s2_fwd2<CIN, COUT, KH, KW, 16>), dim3(a.total_tiles < 2048 ? a.total_tiles : 2048), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_s2_fwd2<CIN, COUT, KH, KW, 16>), dim3(a.total_tiles < capf2 ? a.total_tiles : capf2), dim3(256), 0, s, a);
     }
 }
 
@@ -343,19 +346,28 @@ void s2_fwd_dispatch(const ConvLayer& L, const S2Fwd& a, hipStream_t s) {
 
 template <int CIN, int COUT, int KH, int KW>
 void s2_bwd_launch(S2Bwd a, hipStream_t s) {
+    // 512 workgroups: each ends with Cin*Cout*kh*kw + 2*Cin fp64 atomics, and those dominate beyond that
+    // (measured per step at batch 64: 1536 -> 286 us, 512 -> 274 us)
+    const int cap2 = 512, caps = 512;
     if constexpr (CIN * COUT * KH * KW <= 72) {
         // direct variant: one input pixel per thread, no LDS staging
         if (a.W > 32) {
             a.tiles_x = (a.W + 63) / 64;
             a.tiles_y = (a.H + 3) / 4;
             a.total_tiles = a.B * a.tiles_x * a.tiles_y;
-            hipLaunchKernelGGL((k_s2_bwd2<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < 1536 ? a.total_tiles : 1536), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_s2_bwd2<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < cap2 ? a.total_tiles : cap2), dim3(256), 0, s, a);
         } else {
             a.tiles_x = (a.W + 31) / 32;
             a.tiles_y = (a.H + 7) / 8;
             a.total_tiles = a.B * a.tiles_x * a.tiles_y;
-            hipLaunchKernelGGL((k_s2_bwd2<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < 1536 ? a.total_tiles : 1536), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_s2_bwd2<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < cap2 ? a.total_tiles : cap2), dim3(256), 0, s, a);
         }
+    } else if constexpr (CIN == 8 && CIN * COUT * KH * KW / 4 <= 72) {
+        // channels split over the 4 waves: 2 per thread, 64 pixels (32 x 2) per workgroup pass
+        a.tiles_x = (a.W + 31) / 32;
+        a.tiles_y = (a.H + 1) / 2;
+        a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+        hipLaunchKernelGGL((k_s2_bwd_split<CIN, 2, COUT, KH, KW, 32>), dim3(a.total_tiles < caps ? a.total_tiles : caps), dim3(256), 0, s, a);
     } else {
         constexpr int CT = (CIN % 2 == 0 && CIN != 6) ? 2 : 3;   // input channels per thread
         constexpr int CG = CIN / CT;                              // ci-groups per workgroup
@@ -624,7 +636,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             }
             const int wtiles = ((L.cin + 15) / 16) * ((L.cout * L.kh * L.kw + 15) / 16);
             const int steps = (B * L.hin * L.win + 3) / 4;
-            int chunks = 1024 / wtiles;
+            int chunks = 2048 / wtiles;
             if (chunks < 1) chunks = 1;
             int per = (steps + chunks - 1) / chunks;
             per = (per + 31) / 32 * 32;

@@ -731,4 +731,162 @@ __global__ void __launch_bounds__(256) k_s2_bwd2(S2Bwd a) {
     }
 }
 
+
+// ---- direct (LDS-free) fused backward with the input channels split over the waves ---------------
+// For Cin*Cout*kh*kw too large for one thread's registers (8->4, k3: 288 weight-gradient
+// accumulators): wave w of the workgroup owns input channels [CT*g, CT*(g+1)), g = w mod CG, of the
+// SAME pixels as the other waves, so each thread keeps CT*Cout*kh*kw accumulators.  The gradient patch
+// is read once per channel group (4x for 8->4; the repeats hit L1/L2).  Replaces the LDS-staged
+// k_s2_bwd (204 VGPRs, two barriers per 64-pixel tile) for these shapes.
+template <int CIN, int CT, int COUT, int KH, int KW, int TWL>
+__global__ void __launch_bounds__(256) k_s2_bwd_split(S2Bwd a) {
+    constexpr int CG = CIN / CT;                 // channel groups = waves that share a pixel tile
+    constexpr int PIX = 256 / CG;                // pixels per tile
+    constexpr int TROWS = PIX / TWL;
+    static_assert(PIX % 64 == 0, "a wave must not straddle channel groups");
+    constexpr int NACC = CT * COUT * KH * KW;
+    constexpr int NRED = NACC + 2 * CT;
+    constexpr int WPG = PIX / 64;                // waves per group
+    __shared__ float4 cout4[COUT];
+    __shared__ float4 cin4[CIN];
+    __shared__ float redf[4 * NRED];
+
+    bn_consts(a.bn_out, cout4, false);
+    bn_consts(a.bn_in, cin4, false);
+    if (blockIdx.x == 0 && a.bg.stats) {
+        for (int c = threadIdx.x; c < a.bg.C; c += 256) {
+            double sb = 0.0, sg = 0.0;
+            for (int sh = 0; sh < kStatShards; sh++) {
+                sb += a.bg.stats[((size_t)sh * a.bg.C + c) * 4 + 2];
+                sg += a.bg.stats[((size_t)sh * a.bg.C + c) * 4 + 3];
+            }
+            a.bg.beta_acc[c] = sb * a.bg.scale;
+            a.bg.gamma_acc[c] = sg * a.bg.scale;
+        }
+    }
+    __syncthreads();
+
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / PIX);   // wave-uniform: weights stay scalar
+    const int pix = threadIdx.x - grp * PIX;
+    const int c0 = grp * CT;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const unsigned HW = a.H * a.W, OHW = a.OH * a.OW;
+    float dw[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) dw[i] = 0.f;
+    float d1[CT], d2[CT];
+#pragma unroll
+    for (int i = 0; i < CT; i++) d1[i] = d2[i] = 0.f;
+
+    for (int t = blockIdx.x; t < a.total_tiles; t += gridDim.x) {
+        const int b = t / tiles;
+        const int tt = t - b * tiles;
+        const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+        const int x = tx * TWL + (pix % TWL);
+        const int y = ty * TROWS + (pix / TWL);
+        if (y >= a.H || x >= a.W) continue;
+        const unsigned poff = (unsigned)y * a.W + x;
+        float av[CT], yraw[CT], ga[CT];
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            yraw[c] = a.ain[(size_t)(b * CIN + c0 + c) * HW + poff];
+            av[c] = yraw[c];
+            if (a.bn_in.mode != BN_NONE) {
+                const float4 k = cin4[c0 + c];
+                av[c] = fmaxf(0.f, fmaf(yraw[c] - k.x, k.y, k.z));
+            }
+            ga[c] = 0.f;
+        }
+        const unsigned pbase = (unsigned)(2 * y) * a.OW + 2 * x;
+        // every load of the pixel's patch is issued before the first use: one memory round trip per
+        // pixel instead of one per output channel
+        float pg[COUT][KH][KW], py[COUT][KH][KW];
+#pragma unroll
+        for (int co = 0; co < COUT; co++) {
+            const float* gp = a.g + (size_t)(b * COUT + co) * OHW + pbase;
+#pragma unroll
+            for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+                for (int kx = 0; kx < KW; kx++) pg[co][ky][kx] = gp[ky * a.OW + kx];
+        }
+        if (a.bn_out.mode == BN_BWD) {
+#pragma unroll
+            for (int co = 0; co < COUT; co++) {
+                const float* yp = a.yout + (size_t)(b * COUT + co) * OHW + pbase;
+#pragma unroll
+                for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < KW; kx++) py[co][ky][kx] = yp[ky * a.OW + kx];
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; co++) {
+            float p[KH][KW];
+            const float4 k = a.bn_out.mode == BN_BWD ? cout4[co] : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+                for (int kx = 0; kx < KW; kx++) {
+                    float gvv = pg[co][ky][kx];
+                    if (a.bn_out.mode == BN_BWD) gvv = k.y * gvv - k.z - (py[co][ky][kx] - k.x) * k.w;
+                    p[ky][kx] = gvv;
+                }
+#pragma unroll
+            for (int c = 0; c < CT; c++) {
+                const float* wc = a.w + ((size_t)(c0 + c) * COUT + co) * KH * KW;
+#pragma unroll
+                for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < KW; kx++) {
+                        ga[c] = fmaf(p[ky][kx], wc[ky * KW + kx], ga[c]);
+                        dw[((c * COUT + co) * KH + ky) * KW + kx] =
+                            fmaf(av[c], p[ky][kx], dw[((c * COUT + co) * KH + ky) * KW + kx]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            float gv = ga[c];
+            if (a.bn_in.mode != BN_NONE) {
+                const float4 k = cin4[c0 + c];
+                const float d = yraw[c] - k.x;
+                gv = fmaf(d, k.y, k.z) > 0.f ? gv : 0.f;
+                d1[c] += gv;
+                d2[c] = fmaf(gv, d * k.w, d2[c]);
+            }
+            a.gin[(size_t)(b * CIN + c0 + c) * HW + poff] = gv;
+        }
+    }
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NACC; i++) {
+        const float s = wave_sum_f(dw[i]);
+        if (lane == 0) redf[wv * NRED + i] = s;
+    }
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+        const float s1 = wave_sum_f(d1[c]), s2 = wave_sum_f(d2[c]);
+        if (lane == 0) {
+            redf[wv * NRED + NACC + 2 * c] = s1;
+            redf[wv * NRED + NACC + 2 * c + 1] = s2;
+        }
+    }
+    __syncthreads();
+    const int shard = blockIdx.x & (kStatShards - 1);
+    for (int i = threadIdx.x; i < CG * NRED; i += 256) {
+        const int gsel = i / NRED, j = i - gsel * NRED;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < WPG; w++) s += (double)redf[(gsel * WPG + w) * NRED + j];
+        if (j < NACC) {
+            const int c = j / (COUT * KH * KW), rest = j - c * (COUT * KH * KW);
+            atomicAdd(&a.wacc[(size_t)shard * a.wacc_stride + (size_t)(gsel * CT + c) * COUT * KH * KW + rest], s);
+        } else if (a.stats_in) {
+            const int jj = j - NACC;
+            atomicAdd(&a.stats_in[((size_t)shard * CIN + gsel * CT + (jj >> 1)) * 4 + 2 + (jj & 1)], s);
+        }
+    }
+}
+
 }  // namespace cae
