@@ -536,7 +536,12 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             f.out = ep.out; f.stats = a.train ? ep.stats : nullptr;
             const int mtiles = (B * f.QH * f.QW + 15) / 16;
             f.ksplit = L.cin >= 48 ? 4 : (L.cin >= 24 ? 2 : 1);
-            f.tiles_per_wave = mtiles >= 8192 ? 2 : 1;
+            // at most ~1024 workgroups over the 4 parities: every workgroup ends with up to 32 fp64 atomics
+            {
+                const int waves_m = 4 / f.ksplit;
+                int tpw = (mtiles * 4 + waves_m * 1024 - 1) / (waves_m * 1024);
+                f.tiles_per_wave = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
+            }
             const int per_block = (4 / f.ksplit) * f.tiles_per_wave;
             dim3 grid((mtiles + per_block - 1) / per_block, 4, (L.cout + 15) / 16);
             ProfScope _p(e, a.train ? "ig_convt_fwd" : "ig_convt_eval", (int)l, f4((double)B * (L.in_elems() + L.out_elems())));
