@@ -68,6 +68,8 @@ SIGNATURES = {
     "cae_normalise_pack": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_float,
                                      C.c_float, C.c_int, _P]),
     "cae_denormalise_f64": (C.c_int, [_P, C.c_int64, C.c_double, C.c_double, _P, _P]),
+    "cae_bswap32": (C.c_int, [_P, C.c_int64, _P]),
+    "cae_metric_sums": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, _P, _P]),
 }
 
 _lib = None

@@ -1455,4 +1455,29 @@ int cae_denormalise_f64(const float* y, int64_t n, double vmin, double range, do
     return CAE_OK;
 }
 
+int cae_metric_sums(const float* y, const float* actual, const float* mask, int64_t n_inst, int64_t inst_elems,
+                    double vmin, double range, double* sums, void* hip_stream) {
+    if (!y || !actual || !sums || n_inst < 1 || inst_elems < 1 || n_inst > 65535)
+        return fail(CAE_ERR_ARG, "cae_metric_sums: bad argument");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIP_TRY(hipMemsetAsync(sums, 0, (size_t)n_inst * 8 * sizeof(double), s));
+    int chunks = (int)((inst_elems + 256 * 16 - 1) / (256 * 16));
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(k_metric_sums, dim3(chunks, (unsigned)n_inst), dim3(256), 0, s, y, actual, mask,
+                       (long long)inst_elems, vmin, range, sums);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_bswap32(void* x, int64_t n, void* hip_stream) {
+    if (!x || n < 0 || ((uintptr_t)x & 15)) return fail(CAE_ERR_ARG, "cae_bswap32: bad argument (16-byte aligned device pointer)");
+    if (n == 0) return CAE_OK;
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_bswap32, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream, (unsigned*)x, (long long)n);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
 }  // extern "C"

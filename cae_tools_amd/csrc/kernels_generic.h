@@ -711,4 +711,48 @@ __global__ void __launch_bounds__(256) k_denorm_f64(const float* __restrict__ y,
         out[i] = __dadd_rn(vmin, __dmul_rn((double)y[i], range));
 }
 
+// model_metric.py:47-71 per instance: sums[inst][8] += {n, Σa', Σe', Σa'², Σe'², Σa'e', Σ|a-e|, Σ(a-e)²} over the
+// pixels whose mask is non-zero, with e = vmin + (double)y*range (the denormalised score of base_model.py:90) and
+// a' = a - vmin, e' = e - vmin (shifted so the second moments do not cancel).  grid (chunks, n_inst), block 256.
+__global__ void __launch_bounds__(256) k_metric_sums(const float* __restrict__ y, const float* __restrict__ a,
+                                                      const float* __restrict__ mask, long long elems, double vmin,
+                                                      double range, double* __restrict__ sums) {
+    __shared__ double red[4];
+    const long long base = (long long)blockIdx.y * elems;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < elems; i += (long long)gridDim.x * 256) {
+        if (mask && mask[base + i] == 0.f) continue;
+        const double e = __dadd_rn(vmin, __dmul_rn((double)y[base + i], range));
+        const double av = (double)a[base + i];
+        const double d = av - e, as = av - vmin, es = e - vmin;
+        acc[0] += 1.0;
+        acc[1] += as;
+        acc[2] += es;
+        acc[3] += as * as;
+        acc[4] += es * es;
+        acc[5] += as * es;
+        acc[6] += fabs(d);
+        acc[7] += d * d;
+    }
+    for (int k = 0; k < 8; k++) {
+        const double t = block_sum(acc[k], red);
+        if (threadIdx.x == 0 && t != 0.0) atomicAdd(&sums[(size_t)blockIdx.y * 8 + k], t);
+    }
+}
+
+// NetCDF-3 stores big-endian words: swap n 32-bit words in place (16 bytes per lane per trip)
+__global__ void __launch_bounds__(256) k_bswap32(unsigned* __restrict__ x, long long n) {
+    const long long n4 = n >> 2;
+    uint4* x4 = reinterpret_cast<uint4*>(x);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        uint4 v = x4[i];
+        v.x = __builtin_bswap32(v.x);
+        v.y = __builtin_bswap32(v.y);
+        v.z = __builtin_bswap32(v.z);
+        v.w = __builtin_bswap32(v.w);
+        x4[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) x[(n4 << 2) + threadIdx.x] = __builtin_bswap32(x[(n4 << 2) + threadIdx.x]);
+}
+
 }  // namespace cae

@@ -5,8 +5,9 @@ touches only a small duck-typed surface of them: ds[name] -> .shape/.dims/.value
 assignment, ds.dims, to_netcdf, open_mfdataset(concat_dim=..., combine="nested").  xarray is not
 a dependency of this package (and is absent from the build image): Dataset/DataArray below
 provide exactly that surface over numpy arrays, and every model entry point accepts either these
-or real xarray objects.  Files are NetCDF-3 classic / 64-bit-offset through scipy.io.netcdf_file;
-NetCDF-4 (HDF5) files need xarray + netCDF4/h5netcdf, which open_dataset uses when importable.
+or real xarray objects.  Files are NetCDF-3 classic / 64-bit-offset through the package's own reader /
+writer (netcdf3.py: struct-parsed header, memory-mapped big-endian slabs); NetCDF-4 (HDF5) files need
+xarray + netCDF4/h5netcdf, which open_dataset uses when importable.
 """
 import os
 from collections import OrderedDict
@@ -32,15 +33,24 @@ class DataArray:
 
     @property
     def values(self):
+        """native-endian numpy array (a file-backed big-endian view is converted once, on first use)"""
+        if self._data.dtype.byteorder == ">":
+            self._data = self._data.astype(self._data.dtype.newbyteorder("="))
         return self._data
 
     @property
     def data(self):
+        return self.values
+
+    @property
+    def raw_values(self):
+        """the array as stored (possibly a big-endian read-only view of a NetCDF-3 file mapping): what DSDataset
+        uploads, so that file bytes go to the GPU untouched"""
         return self._data
 
     @property
     def dtype(self):
-        return self._data.dtype
+        return self._data.dtype.newbyteorder("=")
 
     @property
     def size(self):
@@ -51,7 +61,7 @@ class DataArray:
         return self._data.ndim
 
     def __getitem__(self, key):
-        sub = self._data[key]
+        sub = self._data[key]       # stays a view of the file mapping for file-backed variables
         if not isinstance(key, tuple):
             key = (key,)
         dims = [d for d, k in zip(self.dims, list(key) + [slice(None)] * (self.ndim - len(key)))
@@ -62,7 +72,7 @@ class DataArray:
         return self.shape[0]
 
     def __array__(self, dtype=None, copy=None):
-        return self._data if dtype is None else self._data.astype(dtype)
+        return self.values if dtype is None else self.values.astype(dtype)
 
     def __repr__(self):
         return f"<DataArray {dict(zip(self.dims, self.shape))} {self.dtype}>"
@@ -133,31 +143,10 @@ class Dataset:
 # ---------------------------------------------------------------------------------------------
 
 def write_netcdf3(ds, path):
-    from scipy.io import netcdf_file
-    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    with netcdf_file(path, "w", version=2) as f:
-        for d, n in ds.dims.items():
-            f.createDimension(d, int(n))
-        for name, da in ds.data_vars.items():
-            arr = np.asarray(da.values)
-            if arr.dtype == np.float16:
-                arr = arr.astype(np.float32)
-            if arr.dtype == np.int64:  # NetCDF-3 has no 64-bit integers
-                arr = arr.astype(np.int32)
-            if arr.dtype == bool:
-                arr = arr.astype(np.int8)
-            var = f.createVariable(name, arr.dtype.newbyteorder("=").char if arr.dtype.kind != "S" else "c", da.dims)
-            var[...] = arr
-            for k, v in da.attrs.items():
-                try:
-                    setattr(var, k, v)
-                except Exception:
-                    pass
-        for k, v in ds.attrs.items():
-            try:
-                setattr(f, k, v)
-            except Exception:
-                pass
+    """Dataset -> one NetCDF-3 (64-bit offset) file through cae_tools_amd.data.netcdf3"""
+    from . import netcdf3
+    variables = OrderedDict((name, (da.dims, np.asarray(da.raw_values), da.attrs)) for name, da in ds.data_vars.items())
+    netcdf3.write(path, {d: int(n) for d, n in ds.dims.items()}, variables, attributes=ds.attrs, version=2)
 
 
 def _is_hdf5(path):
@@ -166,7 +155,7 @@ def _is_hdf5(path):
 
 
 def open_dataset(path):
-    """One NetCDF file -> Dataset (arrays are copied out of the file mapping)."""
+    """One NetCDF file -> Dataset (arrays are read-only views of the file mapping)."""
     if _is_hdf5(path):
         try:
             import xarray as xr
@@ -174,15 +163,13 @@ def open_dataset(path):
             raise RuntimeError(f"{path} is NetCDF-4/HDF5; reading it needs xarray with netCDF4 or h5netcdf "
                                "(not available) - convert it to NetCDF-3 (ncks -3 / nccopy -k classic)") from ex
         return from_xarray(xr.open_dataset(path))
-    from scipy.io import netcdf_file
-    out = Dataset()
-    with netcdf_file(path, "r", mmap=False) as f:
-        for name, var in f.variables.items():
-            arr = np.array(var[...])
-            if arr.dtype.byteorder == ">":
-                arr = arr.astype(arr.dtype.newbyteorder("="))
-            attrs = {k: getattr(var, k) for k in getattr(var, "_attributes", {})}
-            out[name] = DataArray(arr, dims=tuple(var.dimensions), attrs=attrs)
+    from . import netcdf3
+    f = netcdf3.File(path)
+    out = Dataset(attrs=dict(f.attributes))
+    for name, var in f.variables.items():
+        # big-endian views of the file mapping (kept alive by the arrays): nothing is read until it is used, and
+        # DSDataset uploads contiguous float32 slabs as raw bytes and swaps them on the GPU
+        out[name] = DataArray(var.data, dims=var.dimensions, attrs=dict(var.attributes))
     return out
 
 
@@ -219,6 +206,7 @@ def open_mfdataset(paths, concat_dim="box", combine="nested", **_ignored):
 
 
 def as_numpy(var):
-    """values of a DataArray-like (ours, xarray's, dask-backed) as a numpy array"""
-    v = var.values if hasattr(var, "values") else var
+    """values of a DataArray-like (ours, xarray's, dask-backed) as a numpy array; ours are handed over as stored
+    (a NetCDF-3 variable stays a big-endian view of the file mapping until something converts it)"""
+    v = var.raw_values if hasattr(var, "raw_values") else (var.values if hasattr(var, "values") else var)
     return np.asarray(v)

@@ -401,3 +401,51 @@ def denormalise_f64(y, vmin, vmax):
     check(lib.cae_denormalise_f64(y.data_ptr(), y.numel(), float(vmin), float(vmax) - float(vmin), out.data_ptr(),
                                   torch.cuda.current_stream(y.device).cuda_stream))
     return out
+
+
+def metric_sums(y, actual, mask, vmin, vmax):
+    """cae_metric_sums: per-instance fp64 sums (n, 8) of the denormalised scores `vmin + y*(vmax-vmin)` against
+    `actual` over the pixels where `mask` (same shape, or None = all) is non-zero.  CUDA fp32 tensors (n, ...)."""
+    lib = _lib.load()
+    y, actual = y.contiguous(), actual.contiguous()
+    if y.shape != actual.shape:
+        raise ValueError("The shapes of 'actual' and 'estimates' must match.")
+    n = int(y.shape[0])
+    elems = y.numel() // max(n, 1)
+    if mask is not None:
+        mask = mask.to(device=y.device, dtype=torch.float32).expand(y.shape).contiguous()
+    out = torch.empty((n, 8), dtype=torch.float64, device=y.device)
+    stream = torch.cuda.current_stream(y.device).cuda_stream
+    for lo in range(0, n, 65535):
+        hi = min(n, lo + 65535)
+        check(lib.cae_metric_sums(y[lo:hi].data_ptr(), actual[lo:hi].data_ptr(),
+                                  mask[lo:hi].data_ptr() if mask is not None else None, hi - lo, elems,
+                                  float(vmin), float(vmax) - float(vmin), out[lo:hi].data_ptr(), stream))
+    return out
+
+
+_STAGE_BYTES = 64 << 20
+
+
+def upload_f32(arr, device):
+    """numpy (N,...) array -> fp32 CUDA tensor.  A C-contiguous big-endian float32 array (a NetCDF-3 slab, usually a
+    view of the file mapping) is copied as raw bytes through a pinned staging buffer and byte-swapped on the GPU
+    (cae_bswap32); anything else is converted by numpy first."""
+    import numpy as np
+    arr = np.asarray(arr)
+    if not (arr.dtype == np.dtype(">f4") and arr.dtype.byteorder == ">" and arr.flags.c_contiguous and arr.size > 0):
+        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device)
+    lib = _lib.load()
+    out = torch.empty(arr.shape, dtype=torch.float32, device=device)
+    words = out.view(-1).view(torch.int32)
+    src = arr.reshape(-1).view(np.uint8)
+    nbytes = src.size
+    stage = torch.empty(min(nbytes, _STAGE_BYTES), dtype=torch.uint8).pin_memory()
+    stage_np = stage.numpy()
+    dst_bytes = words.view(torch.uint8)
+    for lo in range(0, nbytes, _STAGE_BYTES):
+        hi = min(nbytes, lo + _STAGE_BYTES)
+        stage_np[:hi - lo] = src[lo:hi]
+        dst_bytes[lo:hi].copy_(stage[:hi - lo], non_blocking=False)
+    check(lib.cae_bswap32(words.data_ptr(), words.numel(), torch.cuda.current_stream(device).cuda_stream))
+    return out

@@ -1,8 +1,8 @@
 """BaseModel — shared model plumbing with the reference's public surface
 (src/cae_tools/models/base_model.py): model id (:33,56-61), io-spec accessors (:35-54),
 evaluate (:69-100), apply (:102-152), dump_metrics (:154-157), save/load of input_spec.json /
-output_spec.json (:162-180).  Scoring and denormalisation run on the GPU through the engine;
-metrics stay on the host as in the reference."""
+output_spec.json (:162-180).  Scoring, denormalisation and the metric reductions run on the GPU
+through libcae_hip; only per-case sums and the final fp64 predictions cross PCIe."""
 import json
 import os
 import uuid
@@ -12,7 +12,7 @@ import torch
 
 from ..data.arrays import DataArray
 from .ds_dataset import DSDataset
-from .model_metric import ModelMetric
+from .model_metric import DeviceModelMetric, ModelMetric  # noqa: F401
 
 
 def _make_data_array(like_ds, data, dims):
@@ -63,17 +63,15 @@ class BaseModel:
         raise NotImplementedError
 
     def evaluate(self, dataset, device=None):
-        """score every case, denormalise, and pool the reference's metrics (:69-100).  The mask is
-        all ones for ConvAEModel (the reference builds it with the INPUT's shape, which cannot index
-        the output; the intended all-pixels mask is used here - SURVEY.md headline fact 3)."""
+        """score every case, denormalise, and pool the reference's metrics (:69-100).  Scores, truth and mask
+        stay on the GPU; cae_metric_sums reduces each case to eight fp64 sums.  The mask is all ones unless the
+        dataset carries a mask variable shaped like the output (the reference builds the default mask with the
+        INPUT's shape, which cannot index the output; the intended all-pixels mask is used - SURVEY.md headline 3)."""
         dataset.set_normalise_output(False)
-        x = dataset.device_inputs()
-        truth = dataset.device_outputs().cpu().numpy()
-        scores = dataset.denormalise_device(self._score_device(x)).cpu().numpy()
-        mm = ModelMetric()
-        ones = np.ones(truth.shape[1:], dtype=np.float32)
-        for i in range(truth.shape[0]):
-            mm.accumulate(truth[i], scores[i], ones)
+        truth = dataset.device_outputs()
+        scores = self._score_device(dataset.device_inputs())
+        mm = DeviceModelMetric()
+        mm.accumulate(truth, scores, dataset.device_mask(), dataset.min_output, dataset.max_output)
         return mm.get_metrics()
 
     def apply(self, score_ds, input_variables, prediction_variable="model_output",

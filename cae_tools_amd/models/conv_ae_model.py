@@ -23,6 +23,7 @@ from .model_sizer import create_model_spec, ModelSpec
 from .ds_dataset import DSDataset
 from .encoder import Encoder
 from .decoder import Decoder
+from ..utils.model_database import ModelDatabase
 
 
 def _index_batches(n, batch_size):
@@ -60,10 +61,7 @@ class ConvAEModel(BaseModel):
         self.spec = None
         self.history = {"train_loss": [], "test_loss": [], "nr_epochs": 0}
         self.optim = None
-        self.db = None
-        if database_path:
-            # experiment bookkeeping (utils/model_database.py) is outside the hot path
-            raise NotImplementedError("database_path: the sqlite tracking database is not part of cae_tools_amd")
+        self.db = ModelDatabase(database_path) if database_path else None   # conv_ae_model.py:75
         self._engine = None
 
     # ---- persistence ---------------------------------------------------------------------
@@ -223,6 +221,10 @@ class ConvAEModel(BaseModel):
         self.history["nr_epochs"] = self.history["nr_epochs"] + self.nr_epochs
         print("elapsed:" + str(elapsed))
 
+        if self.db:     # :343-345
+            self.db.add_training_result(self.get_model_id(), "ConvAE", output_variable, input_variables, self.summary(),
+                                        model_path, training_paths, train_loss, testing_paths, test_loss,
+                                        self.get_parameters(), self.spec.save())
         if model_path:
             self.save(model_path)
         else:
@@ -231,6 +233,8 @@ class ConvAEModel(BaseModel):
         metrics = {"test": self.evaluate(test_ds), "train": self.evaluate(train_ds)}
         self.dump_metrics("Test Metrics", metrics["test"])
         self.dump_metrics("Train Metrics", metrics["train"])
+        if self.db:     # :358-359
+            self.db.add_evaluation_result(self.get_model_id(), training_paths, testing_paths, metrics)
         return metrics
 
     def summary(self):

@@ -75,7 +75,7 @@ class DSDataset(torch.utils.data.Dataset):
         arr = as_numpy(da)
         if arr.ndim != 4:
             raise ValueError(f"variables must be 4-D (case, channel, y, x); got shape {arr.shape}")
-        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(dev)
+        return _eng.upload_f32(arr, dev)
 
     # -- reference accessors ---------------------------------------------------------------
     def set_normalise_output(self, normalise_out):
@@ -134,6 +134,15 @@ class DSDataset(torch.utils.data.Dataset):
             torch.cuda.synchronize(t.device)
             self._t, self._t_norm_flag = t, self.normalise_out
         return self._t
+
+    def device_mask(self):
+        """mask variable as an fp32 CUDA tensor broadcastable to the output, or None (= every pixel)"""
+        if self.mask_da is None or self.mask_da.size == 0 or self._raw_out is None:
+            return None
+        m = torch.from_numpy(np.ascontiguousarray(as_numpy(self.mask_da), dtype=np.float32)).to(self._raw_out.device)
+        while m.dim() < self._raw_out.dim():
+            m = m.unsqueeze(1)
+        return m
 
     # -- torch Dataset protocol ---------------------------------------------------------------
     def __getitem__(self, index):

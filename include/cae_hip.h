@@ -15,6 +15,8 @@
  *   models/ds_dataset.py:43-67      NaN count / nanmin / nanmax   -> cae_scan_f32
  *   models/ds_dataset.py:99-113,137-147 normalise + channel concat -> cae_normalise_pack
  *   models/ds_dataset.py:131-135    denormalise_output            -> cae_denormalise_f64
+ *   cli/train_cae.py:58-59          xr.open_mfdataset -> float32 batches (big-endian NetCDF-3 slabs) -> cae_bswap32
+ *   models/model_metric.py:25-71    ModelMetric (base_model.py:69-100 evaluate) -> cae_metric_sums
  *
  * Conventions: plain pointers and sizes only.  Every pointer named *_dev is DEVICE memory
  * owned by the caller (the Python host allocates it as torch tensors and passes data_ptr());
@@ -196,6 +198,18 @@ int cae_normalise_pack(const float* src_dev, int64_t n, int c_src, int64_t hw, f
 /* ds_dataset.py:131-135 on base_model.py:123's float64 array: out = vmin + ((double)y * range). */
 int cae_denormalise_f64(const float* y_dev, int64_t n, double vmin, double range, double* out_dev,
                         void* hip_stream);
+
+/* cli/train_cae.py:58-59 / ds_dataset.py:137-147: a NetCDF-3 variable is a contiguous big-endian slab; the host
+ * copies it to the device as raw bytes and this swaps n 32-bit words in place (x_dev 16-byte aligned). */
+int cae_bswap32(void* x_dev, int64_t n, void* hip_stream);
+
+/* model_metric.py:25-71 as used by base_model.py:69-100: per instance i of n_inst (each inst_elems
+ * floats of y, actual and — unless NULL — mask), over the pixels with mask != 0:
+ *   sums[i] = {n, S(a'), S(e'), S(a'^2), S(e'^2), S(a'e'), S|a-e|, S(a-e)^2},  e = vmin + (double)y*range,
+ *   a' = a - vmin, e' = e - vmin  (fp64; sums_dev (n_inst, 8) is cleared by the call).  The host pools
+ *   mse/rmse/mae over all instances and averages the per-instance Pearson r.  n_inst <= 65535 per call. */
+int cae_metric_sums(const float* y_dev, const float* actual_dev, const float* mask_dev, int64_t n_inst,
+                    int64_t inst_elems, double vmin, double range, double* sums_dev, void* hip_stream);
 
 #ifdef __cplusplus
 }

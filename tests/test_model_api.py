@@ -157,3 +157,42 @@ def test_dataset_errors_match_reference_messages():
     with pytest.raises(ValueError) as ei:
         DSDataset(Dataset({"lowres": DataArray(bad_in, dims=("n", "c_lowres", "y", "x")), "hires": ds["hires"]}), ["lowres"], "hires")
     assert str(ei.value) == msgs["nan_input_message"]
+
+
+def test_evaluate_on_device_matches_host_metric_and_database(tmp_path):
+    """BaseModel.evaluate (base_model.py:69-100) through cae_metric_sums == the host ModelMetric fed with the same
+    scores; with database_path the training and evaluation rows are logged (conv_ae_model.py:343-345,358-359)"""
+    import sqlite3
+    from cae_tools_amd.data import datagen
+    from cae_tools_amd.models.conv_ae_model import ConvAEModel
+    from cae_tools_amd.models.ds_dataset import DSDataset
+    from cae_tools_amd.models.model_metric import ModelMetric
+    train = datagen.generate("circle", 12, seed=1)
+    test = datagen.generate("circle", 5, seed=2)
+    db_path = str(tmp_path / "track.db")
+    torch.manual_seed(3)
+    mt = ConvAEModel(batch_size=4, nr_epochs=2, test_interval=1, fc_size=8, encoded_dim_size=4, database_path=db_path)
+    with redirect_stdout(io.StringIO()):
+        metrics = mt.train(["lowres"], "hires", train, test, training_paths="tr.nc", testing_paths="te.nc")
+    ds = DSDataset(test, ["lowres"], "hires")
+    ds.set_normalisation_parameters(mt.normalisation_parameters)
+    scores = np.zeros(test["hires"].shape)
+    x = ds.device_inputs()
+    mt.score([x[0:4], x[4:5]], scores)                      # reference-style host scoring (:223-239), batch_size 4
+    scores = ds.denormalise_output(scores, force=True)
+    mm = ModelMetric()
+    truth = np.asarray(test["hires"].values)
+    for i in range(truth.shape[0]):
+        mm.accumulate(truth[i], scores[i], np.ones(truth.shape[1:]))
+    want = mm.get_metrics()
+    for k in want:
+        assert metrics["test"][k] == pytest.approx(float(want[k]), rel=1e-9), k
+    conn = sqlite3.connect(db_path)
+    (mid, mtype, target, inputs, tl) = conn.execute(
+        "SELECT model_id, model_type, target_variable, input_variables, train_loss FROM MODEL_TRAINING").fetchone()
+    assert (mid, mtype, target, json.loads(inputs)) == (mt.get_model_id(), "ConvAE", "hires", ["lowres"])
+    assert tl == pytest.approx(mt.history["train_loss"][-1])
+    (emid, etr, ete, em) = conn.execute("SELECT model_id, train_path, test_path, metrics FROM MODEL_EVALUATIONS").fetchone()
+    assert (emid, etr, ete) == (mid, "tr.nc", "te.nc")
+    assert json.loads(em)["test"]["mse"] == pytest.approx(metrics["test"]["mse"])
+    conn.close()
