@@ -70,6 +70,30 @@ SIGNATURES = {
     "cae_denormalise_f64": (C.c_int, [_P, C.c_int64, C.c_double, C.c_double, _P, _P]),
     "cae_bswap32": (C.c_int, [_P, C.c_int64, _P]),
     "cae_metric_sums": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, _P, _P]),
+    # ---- include/cae_unet.h ----
+    "unet_engine_create": (C.c_int, [C.POINTER(LayerSpecC), C.c_int, C.POINTER(LayerSpecC), C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.POINTER(C.c_void_p)]),
+    "unet_engine_destroy": (None, [_P]),
+    "unet_param_count": (C.c_int64, [_P]),
+    "unet_buffer_count": (C.c_int64, [_P]),
+    "unet_tensor_count": (C.c_int, [_P]),
+    "unet_tensor_info": (C.c_int, [_P, C.c_int, _P]),
+    "unet_workspace_bytes": (C.c_int64, [_P]),
+    "unet_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64]),
+    "unet_set_stream": (C.c_int, [_P, _P]),
+    "unet_set_kernel_mode": (C.c_int, [_P, C.c_int]),
+    "unet_set_hyper": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.c_uint32]),
+    "unet_set_step": (C.c_int, [_P, C.c_int64]),
+    "unet_set_dataset": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_int64]),
+    "unet_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
+    "unet_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "unet_eval_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
+    "unet_score": (C.c_int, [_P, _P, C.c_int, _P]),
+    "unet_loss_slots": (C.c_int, [_P]),
+    "unet_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "unet_sync": (C.c_int, [_P]),
+    "unet_debug_read": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
 }
 
 _lib = None

@@ -1,6 +1,10 @@
 """Build libcae_hip.so in-tree with hipcc for gfx950.
 
-    python -m cae_tools_amd.build            # (re)build if sources are newer than the library
+    python -m cae_tools_amd.build            # (re)build what is older than its sources
+    python -m cae_tools_amd.build --force
+
+Each .hip source is compiled to an object under csrc/_obj/ (only when it or one of its headers changed, the
+sources in parallel), then the objects are linked into csrc/libcae_hip.so.
 """
 import os
 import shutil
@@ -10,10 +14,16 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+INC = os.path.join(ROOT, "include")
 LIB = os.path.join(CSRC, "libcae_hip.so")
-SOURCES = ["engine.hip"]
-HEADERS = ["kernels_generic.h", "kernels_s2.h", "kernels_gemm.h", "kernels_igemm.h"]
 ARCH = "gfx950"
+# source -> headers it includes (csrc/ or include/)
+SOURCES = {
+    "engine.hip": ["kernels_generic.h", "kernels_s2.h", "kernels_gemm.h", "kernels_igemm.h", "cae_hip.h"],
+    "unet_engine.hip": ["kernels_unet.h", "kernels_unet_mfma.h", "cae_unet.h", "cae_hip.h"],
+}
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-cuda-compat", "-Wno-pass-failed"]
 
 
 def _hipcc():
@@ -23,20 +33,44 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build libcae_hip.so")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _path(name):
+    p = os.path.join(CSRC, name)
+    return p if os.path.exists(p) else os.path.join(INC, name)
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "cae_hip.h")]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+
+
+def needs_build():
+    if any(_stale(_obj(s), [_path(s)] + [_path(h) for h in hs]) for s, hs in SOURCES.items()):
+        return True
+    return _stale(LIB, [_obj(s) for s in SOURCES])
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-cuda-compat", "-Wno-pass-failed",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB + ".tmp"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    for src, headers in SOURCES.items():
+        if force or _stale(_obj(src), [_path(src)] + [_path(h) for h in headers]):
+            cmd = [hipcc] + FLAGS + ["-I" + INC, "-I" + CSRC, "-c", _path(src), "-o", _obj(src)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            jobs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, p in jobs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for " + ", ".join(failed))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + [_obj(s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -33,6 +33,13 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+}  // namespace
+
+// shared with unet_engine.hip: sets the message cae_last_error() returns for the calling thread
+void cae_detail_set_error(const char* msg) { g_err = msg; }
+
+namespace {
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \

@@ -1,0 +1,679 @@
+// kernels_unet.h — gfx950 kernels of the UNET path (reference: src/cae_tools/models/unet.py).
+//
+// Unlike the ConvAE path (3.8 FLOP/B, everything fused into a handful of streaming kernels) the UNET
+// layers are wide (32..256 channels, 4x4 kernels): the convolutions are GEMMs that dominate the step,
+// and the element-wise work between them (BatchNorm, ReLU, dropout, channel attention, skip concat)
+// is a few passes over tensors the GEMMs have to read anyway.  So the convolutions here are PURE
+// (plain tensors in, plain tensors out, bias in the epilogue) and the glue is a set of small
+// element-wise / reduction kernels.
+//
+// This file holds the shape-generic kernels (any kernel size, stride, padding; one thread per output)
+// and all of the glue; kernels_unet_mfma.h holds the LDS-tiled MFMA kernels for the 4x4 / stride 2 /
+// pad 1 layers that carry the FLOPs.  Both are checked against the CPU oracle.
+//
+// Conv primitives, on a small map S (B,Cs,Hs,Ws), a big map L (B,Cl,Hl,Wl), weights w[cs][cl][ky][kx]
+// (PyTorch's layout for Conv2d (Cout,Cin,kh,kw) with S = output and for ConvTranspose2d
+// (Cin,Cout,kh,kw) with S = input), stride s and padding p:
+//   down : S[cs][y][x]        = bias + sum_cl,ky,kx L[cl][y*s+ky-p][x*s+kx-p] * w     (Conv2d fwd, ConvT dgrad)
+//   up   : L[cl][Y][X]        = bias + sum_cs,ky,kx S[cs][(Y+p-ky)/s][(X+p-kx)/s] * w (ConvT fwd, Conv2d dgrad)
+//   wgrad: dw[cs][cl][ky][kx] = sum_b,y,x S[cs][y][x] * L[cl][y*s+ky-p][x*s+kx-p]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace unet {
+
+// sum of v over the block (any multiple of 64 threads), valid in thread 0.  red: LDS scratch of blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)((blockDim.x + 63) >> 6); i++) t += red[i];
+    return t;
+}
+
+struct Geom {
+    int B, Cs, Hs, Ws, Cl, Hl, Wl, kh, kw, s, p;
+};
+
+// ---------------------------------------------------------------------------------------------
+// dropout: keep(idx) is a pure function of (key, idx); key = pcg(pcg(seed + 0x9E3779B9*site) ^ step)
+// is formed on the host.  oracle/unet_oracle.py:dropout_keep is the same function in numpy.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t pcg(uint32_t v) {
+    const uint32_t state = v * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
+struct Drop {
+    uint32_t key;
+    uint32_t thr;   // keep iff hash >= thr
+    float scale;    // 1 / (1 - p)
+    int on;
+};
+
+__device__ __forceinline__ float drop_factor(const Drop& d, unsigned long long idx) {
+    if (!d.on) return 1.f;
+    const uint32_t hi = pcg(d.key + (uint32_t)(idx >> 32));
+    const uint32_t r = pcg((uint32_t)idx ^ hi);
+    return r >= d.thr ? d.scale : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic convolutions (fallback for any geometry)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_down(Geom g, const float* __restrict__ L, const float* __restrict__ w,
+                                              const float* __restrict__ bias, float* __restrict__ S) {
+    const long long total = (long long)g.B * g.Cs * g.Hs * g.Ws;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int x = (int)(idx % g.Ws);
+        long long r = idx / g.Ws;
+        const int y = (int)(r % g.Hs);
+        r /= g.Hs;
+        const int cs = (int)(r % g.Cs);
+        const int b = (int)(r / g.Cs);
+        float acc = bias ? bias[cs] : 0.f;
+        const float* wp = w + (size_t)cs * g.Cl * g.kh * g.kw;
+        for (int cl = 0; cl < g.Cl; cl++) {
+            const float* lp = L + ((size_t)b * g.Cl + cl) * g.Hl * g.Wl;
+            for (int ky = 0; ky < g.kh; ky++) {
+                const int Y = y * g.s + ky - g.p;
+                if (Y < 0 || Y >= g.Hl) continue;
+                for (int kx = 0; kx < g.kw; kx++) {
+                    const int X = x * g.s + kx - g.p;
+                    if (X < 0 || X >= g.Wl) continue;
+                    acc = fmaf(lp[(size_t)Y * g.Wl + X], wp[(cl * g.kh + ky) * g.kw + kx], acc);
+                }
+            }
+        }
+        S[idx] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_up(Geom g, const float* __restrict__ S, const float* __restrict__ w,
+                                            const float* __restrict__ bias, float* __restrict__ L) {
+    const long long total = (long long)g.B * g.Cl * g.Hl * g.Wl;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int X = (int)(idx % g.Wl);
+        long long r = idx / g.Wl;
+        const int Y = (int)(r % g.Hl);
+        r /= g.Hl;
+        const int cl = (int)(r % g.Cl);
+        const int b = (int)(r / g.Cl);
+        float acc = bias ? bias[cl] : 0.f;
+        for (int ky = 0; ky < g.kh; ky++) {
+            const int ty = Y + g.p - ky;
+            if (ty < 0 || ty % g.s) continue;
+            const int y = ty / g.s;
+            if (y >= g.Hs) continue;
+            for (int kx = 0; kx < g.kw; kx++) {
+                const int tx = X + g.p - kx;
+                if (tx < 0 || tx % g.s) continue;
+                const int x = tx / g.s;
+                if (x >= g.Ws) continue;
+                const float* sp = S + (size_t)b * g.Cs * g.Hs * g.Ws + (size_t)y * g.Ws + x;
+                const float* wp = w + ((size_t)cl * g.kh + ky) * g.kw + kx;
+                for (int cs = 0; cs < g.Cs; cs++)
+                    acc = fmaf(sp[(size_t)cs * g.Hs * g.Ws], wp[(size_t)cs * g.Cl * g.kh * g.kw], acc);
+            }
+        }
+        L[idx] = acc;
+    }
+}
+
+// grid (Cs*Cl*kh*kw, nsplit): block = one weight, a slice of the batch; fp64 atomics into acc
+__global__ void __launch_bounds__(256) k_wgrad(Geom g, const float* __restrict__ S, const float* __restrict__ L,
+                                               double* __restrict__ acc) {
+    __shared__ double red[4];
+    int wi = blockIdx.x;
+    const int kx = wi % g.kw;
+    wi /= g.kw;
+    const int ky = wi % g.kh;
+    wi /= g.kh;
+    const int cl = wi % g.Cl;
+    const int cs = wi / g.Cl;
+    const int per = g.Hs * g.Ws;
+    const long long total = (long long)g.B * per;
+    double sum = 0.0;
+    for (long long e = (long long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long long)gridDim.y * 256) {
+        const int b = (int)(e / per);
+        const int r = (int)(e - (long long)b * per);
+        const int y = r / g.Ws, x = r - y * g.Ws;
+        const int Y = y * g.s + ky - g.p, X = x * g.s + kx - g.p;
+        if (Y < 0 || Y >= g.Hl || X < 0 || X >= g.Wl) continue;
+        sum += (double)(S[((size_t)b * g.Cs + cs) * per + r] * L[(((size_t)b * g.Cl + cl) * g.Hl + Y) * g.Wl + X]);
+    }
+    const double t = block_sum(sum, red);
+    if (threadIdx.x == 0 && t != 0.0) atomicAdd(&acc[blockIdx.x], t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-channel reductions and BatchNorm (2-d: (B,C,HW); 1-d: HW = 1)
+// ---------------------------------------------------------------------------------------------
+
+// sums[c*sstride + 0..1] += sum x, sum x^2 over (b, i) of x[b*bs + c*HW + i] (the squares only if want_sq).
+// grid (chunks, C)
+__global__ void __launch_bounds__(256) k_chan_sums(const float* __restrict__ x, long long bs, int B, int HW,
+                                                   double* __restrict__ sums, int sstride, int want_sq) {
+    __shared__ double red[4];
+    const int c = blockIdx.y;
+    const long long total = (long long)B * HW;
+    double s1 = 0, s2 = 0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long b = e / HW, i = e - b * HW;
+        const double v = (double)x[b * bs + (long long)c * HW + i];
+        s1 += v;
+        s2 += v * v;
+    }
+    const double t1 = block_sum(s1, red);
+    if (threadIdx.x == 0) atomicAdd(&sums[(size_t)c * sstride], t1);
+    if (want_sq) {
+        const double t2 = block_sum(s2, red);
+        if (threadIdx.x == 0) atomicAdd(&sums[(size_t)c * sstride + 1], t2);
+    }
+}
+
+// batch statistics -> saved {mean, invstd}; running stats updated as torch does (unbiased running_var)
+__global__ void k_bn_finalize(int C, const double* __restrict__ sums, double N, float eps, float momentum,
+                              float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ saved) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[2 * c] / N;
+    double var = sums[2 * c + 1] / N - mean * mean;
+    if (var < 0) var = 0;
+    saved[2 * c] = (float)mean;
+    saved[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    const double unbiased = N > 1 ? var * N / (N - 1) : var;
+    rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + (double)momentum * mean);
+    rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + (double)momentum * unbiased);
+}
+
+// a = dropout(relu(bn(z))), s = relu(bn(z)) (optional).  use_running: mean/var from the running stats.
+// z is read with batch stride zbs; s and a are contiguous (B,C,HW).  grid (chunks, C)
+__global__ void __launch_bounds__(256) k_bn_act(const float* __restrict__ z, long long zbs, int B, int C, int HW,
+                                                const float* __restrict__ saved, const float* __restrict__ rmean,
+                                                const float* __restrict__ rvar, float eps, int use_running,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                Drop d, float* __restrict__ s_out, float* __restrict__ a_out) {
+    const int c = blockIdx.y;
+    const float mean = use_running ? rmean[c] : saved[2 * c];
+    const float invstd = use_running ? 1.f / sqrtf(rvar[c] + eps) : saved[2 * c + 1];
+    const float sc = invstd * gamma[c], sh = beta[c];
+    const long long total = (long long)B * HW;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long b = e / HW, i = e - b * HW;
+        const float v = fmaxf(fmaf(z[b * zbs + (long long)c * HW + i] - mean, sc, sh), 0.f);
+        const unsigned long long o = ((unsigned long long)b * C + c) * HW + i;
+        if (s_out) s_out[o] = v;
+        if (a_out) a_out[o] = v * drop_factor(d, o);
+    }
+}
+
+// backward, pass 1: g = (gA * dropmask + gB) * [bn(z) > 0]; writes g (contiguous), accumulates
+// sums[c][0..1] += sum g, sum g*xhat.  gA / gB may be null; each has its own batch stride.  grid (chunks, C)
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce(const float* __restrict__ gA, long long gAbs,
+                                                       const float* __restrict__ gB, long long gBbs,
+                                                       const float* __restrict__ z, long long zbs, int B, int C, int HW,
+                                                       const float* __restrict__ saved, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, Drop d, float* __restrict__ g_out,
+                                                       double* __restrict__ sums) {
+    __shared__ double red[4];
+    const int c = blockIdx.y;
+    const float mean = saved[2 * c], invstd = saved[2 * c + 1];
+    const float ga = gamma[c], be = beta[c];
+    const long long total = (long long)B * HW;
+    double s1 = 0, s2 = 0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long b = e / HW, i = e - b * HW;
+        const long long ci = (long long)c * HW + i;
+        const float xh = (z[b * zbs + ci] - mean) * invstd;
+        const unsigned long long o = ((unsigned long long)b * C + c) * HW + i;
+        float g = 0.f;
+        if (gA) g = gA[b * gAbs + ci] * drop_factor(d, o);
+        if (gB) g += gB[b * gBbs + ci];
+        if (!(fmaf(xh, ga, be) > 0.f)) g = 0.f;
+        g_out[o] = g;
+        s1 += (double)g;
+        s2 += (double)g * (double)xh;
+    }
+    const double t1 = block_sum(s1, red);
+    const double t2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * c], t1);
+        atomicAdd(&sums[2 * c + 1], t2);
+    }
+}
+
+// backward, pass 2 (in place on g): dz = gamma*invstd*(g - sum_g/N - xhat*sum_gx/N); block x == 0 also
+// adds dgamma = sum g*xhat, dbeta = sum g to the gradient accumulator.  grid (chunks, C)
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(float* __restrict__ g, const float* __restrict__ z, long long zbs,
+                                                      int B, int C, int HW, const float* __restrict__ saved,
+                                                      const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                      double N, double* __restrict__ acc_gamma,
+                                                      double* __restrict__ acc_beta) {
+    const int c = blockIdx.y;
+    const float mean = saved[2 * c], invstd = saved[2 * c + 1];
+    const float k1 = gamma[c] * invstd;
+    const float m1 = (float)(sums[2 * c] / N), m2 = (float)(sums[2 * c + 1] / N);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        acc_gamma[c] += sums[2 * c + 1];
+        acc_beta[c] += sums[2 * c];
+    }
+    const long long total = (long long)B * HW;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long b = e / HW, i = e - b * HW;
+        const float xh = (z[b * zbs + (long long)c * HW + i] - mean) * invstd;
+        const long long o = (b * C + c) * HW + i;
+        g[o] = k1 * (g[o] - m1 - xh * m2);
+    }
+}
+
+// g *= dropmask * [h > 0]  (ReLU + dropout backward where there is no BatchNorm: the second Linear of each stack)
+__global__ void __launch_bounds__(256) k_relu_drop_bwd(float* __restrict__ g, const float* __restrict__ h, long long n, Drop d) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        g[i] = h[i] > 0.f ? g[i] * drop_factor(d, (unsigned long long)i) : 0.f;
+}
+
+// a = dropout(relu(h))  (forward of the same)
+__global__ void __launch_bounds__(256) k_relu_drop(const float* __restrict__ h, long long n, Drop d, float* __restrict__ a) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        a[i] = fmaxf(h[i], 0.f) * drop_factor(d, (unsigned long long)i);
+}
+
+// ---------------------------------------------------------------------------------------------
+// channel attention (unet.py:23-39) and the skip concat (unet.py:157-160)
+// ---------------------------------------------------------------------------------------------
+
+// pool[b*C+c] = {mean, max, (float)argmax} of u[b][c][:].  grid (B*C)
+__global__ void __launch_bounds__(256) k_pool(const float* __restrict__ u, int HW, float* __restrict__ pool) {
+    __shared__ double red[4];
+    __shared__ float smax[256];
+    __shared__ int sarg[256];
+    const float* p = u + (size_t)blockIdx.x * HW;
+    double s = 0;
+    float mx = -INFINITY;
+    int am = 0x7fffffff;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float v = p[i];
+        s += (double)v;
+        if (v > mx) {
+            mx = v;
+            am = i;
+        }
+    }
+    smax[threadIdx.x] = mx;
+    sarg[threadIdx.x] = am;
+    const double t = block_sum(s, red);
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            const float o = smax[threadIdx.x + off];
+            const int oa = sarg[threadIdx.x + off];
+            if (o > smax[threadIdx.x] || (o == smax[threadIdx.x] && oa < sarg[threadIdx.x])) {
+                smax[threadIdx.x] = o;
+                sarg[threadIdx.x] = oa;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        pool[3 * blockIdx.x + 0] = (float)(t / HW);
+        pool[3 * blockIdx.x + 1] = smax[0];
+        pool[3 * blockIdx.x + 2] = __int_as_float(sarg[0]);
+    }
+}
+
+// att[b][c] = sigmoid(sum_r W2[c][r] * (relu(W1[r]·avg) + relu(W1[r]·max)));  hid[b][0..R) = W1·avg, [R..2R) = W1·max
+// grid (B), block 256, dynamic LDS (2C + 2R) floats
+__global__ void __launch_bounds__(256) k_att_fwd(const float* __restrict__ pool, int C, int R, const float* __restrict__ W1,
+                                                 const float* __restrict__ W2, float* __restrict__ att,
+                                                 float* __restrict__ hid) {
+    extern __shared__ float lds_f[];
+    float* avg = lds_f;
+    float* mx = lds_f + C;
+    float* h = lds_f + 2 * C;   // 2R pre-activations
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        avg[c] = pool[3 * ((size_t)b * C + c)];
+        mx[c] = pool[3 * ((size_t)b * C + c) + 1];
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < 2 * R; r += 256) {
+        const float* src = r < R ? avg : mx;
+        const float* wr = W1 + (size_t)(r < R ? r : r - R) * C;
+        float acc = 0.f;
+        for (int c = 0; c < C; c++) acc = fmaf(wr[c], src[c], acc);
+        h[r] = acc;
+        hid[(size_t)b * 2 * R + r] = acc;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float oa = 0.f, om = 0.f;
+        for (int r = 0; r < R; r++) {
+            oa = fmaf(W2[(size_t)c * R + r], fmaxf(h[r], 0.f), oa);
+            om = fmaf(W2[(size_t)c * R + r], fmaxf(h[R + r], 0.f), om);
+        }
+        att[(size_t)b * C + c] = 1.f / (1.f + expf(-(oa + om)));
+    }
+}
+
+// cat[b][c][:] = u[b][c][:] * att[b][c];  cat[b][C+c][:] = skip[b][c][:]
+__global__ void __launch_bounds__(256) k_scale_concat(const float* __restrict__ u, const float* __restrict__ att,
+                                                      const float* __restrict__ skip, int B, int C, int HW,
+                                                      float* __restrict__ cat) {
+    const long long total = (long long)B * 2 * C * HW;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const long long i = o % HW;
+        const long long r = o / HW;
+        const int c2 = (int)(r % (2 * C));
+        const long long b = r / (2 * C);
+        cat[o] = c2 < C ? u[(b * C + c2) * HW + i] * att[b * C + c2] : skip[(b * C + (c2 - C)) * HW + i];
+    }
+}
+
+// da[b*C+c] = sum_i dcat[b][c][i] * u[b][c][i]   (dcat has 2C channels).  grid (B*C)
+__global__ void __launch_bounds__(256) k_att_da(const float* __restrict__ dcat, const float* __restrict__ u, int C, int HW,
+                                                float* __restrict__ da) {
+    __shared__ double red[4];
+    const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+    const float* gp = dcat + ((size_t)b * 2 * C + c) * HW;
+    const float* up = u + (size_t)blockIdx.x * HW;
+    double s = 0;
+    for (int i = threadIdx.x; i < HW; i += 256) s += (double)(gp[i] * up[i]);
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) da[blockIdx.x] = (float)t;
+}
+
+// backward of k_att_fwd for one sample per block: dpool[b*C+c] = {davg, dmax}; weight gradients by fp64 atomics.
+// grid (B), block 256, dynamic LDS (3C + 4R) floats
+__global__ void __launch_bounds__(256) k_att_bwd(const float* __restrict__ pool, const float* __restrict__ att,
+                                                 const float* __restrict__ hid, const float* __restrict__ da, int C, int R,
+                                                 const float* __restrict__ W1, const float* __restrict__ W2,
+                                                 double* __restrict__ accW1, double* __restrict__ accW2,
+                                                 float* __restrict__ dpool) {
+    extern __shared__ float lds_f[];
+    float* avg = lds_f;
+    float* mx = lds_f + C;
+    float* dout = lds_f + 2 * C;        // dL/d(pre-sigmoid)
+    float* h = lds_f + 3 * C;           // 2R pre-activations
+    float* dh = lds_f + 3 * C + 2 * R;  // 2R gradients wrt pre-activations
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        avg[c] = pool[3 * ((size_t)b * C + c)];
+        mx[c] = pool[3 * ((size_t)b * C + c) + 1];
+        const float a = att[(size_t)b * C + c];
+        dout[c] = da[(size_t)b * C + c] * a * (1.f - a);
+    }
+    for (int r = threadIdx.x; r < 2 * R; r += 256) h[r] = hid[(size_t)b * 2 * R + r];
+    __syncthreads();
+    for (int r = threadIdx.x; r < 2 * R; r += 256) {
+        const int rr = r < R ? r : r - R;
+        float acc = 0.f;
+        for (int c = 0; c < C; c++) acc = fmaf(W2[(size_t)c * R + rr], dout[c], acc);
+        dh[r] = h[r] > 0.f ? acc : 0.f;
+    }
+    for (int e = threadIdx.x; e < C * R; e += 256) {
+        const int c = e / R, r = e - c * R;
+        const float v = dout[c] * (fmaxf(h[r], 0.f) + fmaxf(h[R + r], 0.f));
+        if (v != 0.f) atomicAdd(&accW2[e], (double)v);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < R * C; e += 256) {
+        const int r = e / C, c = e - r * C;
+        const float v = dh[r] * avg[c] + dh[R + r] * mx[c];
+        if (v != 0.f) atomicAdd(&accW1[e], (double)v);
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float ga = 0.f, gm = 0.f;
+        for (int r = 0; r < R; r++) {
+            ga = fmaf(W1[(size_t)r * C + c], dh[r], ga);
+            gm = fmaf(W1[(size_t)r * C + c], dh[R + r], gm);
+        }
+        dpool[2 * ((size_t)b * C + c)] = ga;
+        dpool[2 * ((size_t)b * C + c) + 1] = gm;
+    }
+}
+
+// du[b][c][i] = dcat[b][c][i]*att + davg/HW + [i == argmax]*dmax
+__global__ void __launch_bounds__(256) k_scale_bwd(const float* __restrict__ dcat, const float* __restrict__ att,
+                                                   const float* __restrict__ pool, const float* __restrict__ dpool, int B,
+                                                   int C, int HW, float* __restrict__ du) {
+    const long long total = (long long)B * C * HW;
+    const float inv = 1.f / (float)HW;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const long long i = o % HW;
+        const long long bc = o / HW;
+        const long long b = bc / C, c = bc - b * C;
+        float v = dcat[(b * 2 * C + c) * HW + i] * att[bc] + dpool[2 * bc] * inv;
+        if ((int)i == __float_as_int(pool[3 * bc + 2])) v += dpool[2 * bc + 1];
+        du[o] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Linear layers, W[out][in]
+// ---------------------------------------------------------------------------------------------
+
+// out[b][o] = bias[o] + sum_i in[b][i] * W[o][i].  grid (nout, ceil(B/8)), block 256
+__global__ void __launch_bounds__(256) k_lin_fwd(int B, int nin, int nout, const float* __restrict__ in,
+                                                 const float* __restrict__ W, const float* __restrict__ bias,
+                                                 float* __restrict__ out) {
+    __shared__ double red[4];
+    const int o = blockIdx.x, b0 = blockIdx.y * 8;
+    const int nb = min(8, B - b0);
+    const float* wp = W + (size_t)o * nin;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nin; i += 256) {
+        const float wv = wp[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < nb) acc[j] = fmaf(in[(size_t)(b0 + j) * nin + i], wv, acc[j]);
+    }
+    for (int j = 0; j < nb; j++) {
+        const double t = block_sum((double)acc[j], red);
+        if (threadIdx.x == 0) out[(size_t)(b0 + j) * nout + o] = (float)(t + (double)bias[o]);
+    }
+}
+
+// gin[b][i] = sum_o gout[b][o] * W[o][i]
+__global__ void __launch_bounds__(256) k_lin_dgrad(int B, int nin, int nout, const float* __restrict__ gout,
+                                                   const float* __restrict__ W, float* __restrict__ gin) {
+    const long long total = (long long)B * nin;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long b = idx / nin, i = idx - b * nin;
+        const float* gp = gout + b * nout;
+        float acc = 0.f;
+        for (int o = 0; o < nout; o++) acc = fmaf(gp[o], W[(size_t)o * nin + i], acc);
+        gin[idx] = acc;
+    }
+}
+
+// accW[o][i] += sum_b gout[b][o] * in[b][i];  accB[o] += sum_b gout[b][o]
+__global__ void __launch_bounds__(256) k_lin_wgrad(int B, int nin, int nout, const float* __restrict__ gout,
+                                                   const float* __restrict__ in, double* __restrict__ accW,
+                                                   double* __restrict__ accB) {
+    const long long total = (long long)nout * nin;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long o = idx / nin, i = idx - o * nin;
+        float sum = 0.f, bsum = 0.f;
+        for (int b = 0; b < B; b++) {
+            const float gv = gout[(size_t)b * nout + o];
+            sum = fmaf(gv, in[(size_t)b * nin + i], sum);
+            bsum += gv;
+        }
+        accW[idx] += (double)sum;
+        if (i == 0) accB[o] += (double)bsum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss: masked MSE + lambda * (1 - mean masked Pearson r)  (unet.py:316-321,635-678)
+// ---------------------------------------------------------------------------------------------
+
+// dst[b][:] = src[perm ? perm[start+b] : start+b][:]
+__global__ void __launch_bounds__(256) k_gather(const float* __restrict__ src, const int* __restrict__ perm, long long start,
+                                                int B, long long E, float* __restrict__ dst) {
+    const long long total = (long long)B * E;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const long long b = o / E, i = o - b * E;
+        const long long s = perm ? (long long)perm[start + b] : start + b;
+        dst[o] = src[s * E + i];
+    }
+}
+
+struct LossSrc {
+    const float* target;  // dataset (N, C, HW)
+    const float* mask;    // dataset (N, Cm, HW) or nullptr (all ones, counted with C channels)
+    const int* perm;
+    long long start;
+    int Cm;               // 1 or C
+};
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
+
+// ls[(b*C+c)*8 + k] += {sum m, sum m p, sum m t, sum m p^2, sum m t^2, sum m p t, sum (m (p-t))^2}; p = sigmoid(u) or u
+// grid (chunks, B*C)
+__global__ void __launch_bounds__(256) k_loss_sums(const float* __restrict__ u, int apply_sigmoid, LossSrc ls_src, int C,
+                                                   int HW, double* __restrict__ ls) {
+    __shared__ double red[4];
+    const int bc = blockIdx.y;
+    const int b = bc / C, c = bc - b * C;
+    const long long smp = ls_src.perm ? (long long)ls_src.perm[ls_src.start + b] : ls_src.start + b;
+    const float* tp = ls_src.target + (smp * C + c) * HW;
+    const float* mp = ls_src.mask ? ls_src.mask + (smp * ls_src.Cm + (ls_src.Cm == 1 ? 0 : c)) * HW : nullptr;
+    const float* up = u + (size_t)bc * HW;
+    double a[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const double m = mp ? (double)mp[i] : 1.0;
+        const double p = (double)(apply_sigmoid ? sigmoidf(up[i]) : up[i]);
+        const double t = (double)tp[i];
+        const float df = ((float)p - (float)t) * (float)m;   // the reference forms (pred - target) * mask in fp32
+        a[0] += m;
+        a[1] += m * p;
+        a[2] += m * t;
+        a[3] += m * p * p;
+        a[4] += m * t * t;
+        a[5] += m * p * t;
+        a[6] += (double)df * (double)df;
+    }
+    for (int k = 0; k < 7; k++) {
+        const double t = block_sum(a[k], red);
+        if (threadIdx.x == 0 && t != 0.0) atomicAdd(&ls[(size_t)bc * 8 + k], t);
+    }
+}
+
+// one block: loss values out2 = {mse, 1 - mean r} and the gradient coefficients coef[bc] = {k0, k1, k2, k3}:
+//   dL/dp = m*(k0 + k1*t + k2*p) + k3*m^2*(p - t)
+__global__ void __launch_bounds__(256) k_loss_finalize(const double* __restrict__ ls, int B, int C, int Cm, int has_mask,
+                                                       double lambda_p, double* __restrict__ out2,
+                                                       float* __restrict__ coef) {
+    __shared__ double red[4];
+    const int n_bc = B * C;
+    double mtot = 0, sq = 0, rsum = 0;
+    for (int bc = threadIdx.x; bc < n_bc; bc += 256) {
+        const double* s = ls + (size_t)bc * 8;
+        const int c = bc % C;
+        if (!has_mask || Cm == C || c == 0) mtot += s[0];   // torch.sum(mask) counts the mask tensor as stored
+        sq += s[6];
+    }
+    mtot = block_sum(mtot, red);
+    __shared__ double sh_m;
+    if (threadIdx.x == 0) sh_m = mtot;
+    __syncthreads();
+    mtot = sh_m;
+    sq = block_sum(sq, red);
+    for (int bc = threadIdx.x; bc < n_bc; bc += 256) {
+        const double* s = ls + (size_t)bc * 8;
+        const double n = s[0], np = n + 1e-8;
+        const double mup = s[1] / np, mut = s[2] / np;
+        const double vp = (s[3] - 2 * mup * s[1] + mup * mup * n) / np + 1e-8;
+        const double vt = (s[4] - 2 * mut * s[2] + mut * mut * n) / np + 1e-8;
+        const double sp = sqrt(vp), st = sqrt(vt);
+        const double A = s[5] - mup * s[2] - mut * s[1] + mup * mut * n;
+        const double r = A / (sp * st) / n;
+        rsum += r;
+        if (coef) {
+            const double kappa = -lambda_p / (double)n_bc;
+            const double q = 1.0 / (sp * st * n);
+            const double Sp = s[1] - mup * n, St = s[2] - mut * n;   // sum m (p - mup), sum m (t - mut)
+            const double e1 = q;
+            const double e2 = -q * A / (vp * np);
+            const double e0 = q * (-mut - St / np) + e2 * (-mup - Sp / np);
+            coef[4 * bc + 0] = (float)(kappa * e0);
+            coef[4 * bc + 1] = (float)(kappa * e1);
+            coef[4 * bc + 2] = (float)(kappa * e2);
+            coef[4 * bc + 3] = (float)(2.0 / mtot);
+        }
+    }
+    rsum = block_sum(rsum, red);
+    if (threadIdx.x == 0) {
+        out2[0] = sq / mtot;
+        out2[1] = 1.0 - rsum / (double)n_bc;
+    }
+}
+
+// du = dL/dp * p * (1 - p),  p = sigmoid(u).  grid-stride over (B*C*HW)
+__global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ u, LossSrc ls_src, int B, int C, int HW,
+                                                   const float* __restrict__ coef, float* __restrict__ du) {
+    const long long total = (long long)B * C * HW;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const long long i = o % HW;
+        const long long bc = o / HW;
+        const long long b = bc / C, c = bc - b * C;
+        const long long smp = ls_src.perm ? (long long)ls_src.perm[ls_src.start + b] : ls_src.start + b;
+        const float t = ls_src.target[(smp * C + c) * HW + i];
+        const float m = ls_src.mask ? ls_src.mask[(smp * ls_src.Cm + (ls_src.Cm == 1 ? 0 : c)) * HW + i] : 1.f;
+        const float p = sigmoidf(u[o]);
+        const float4 k = reinterpret_cast<const float4*>(coef)[bc];
+        const float dp = m * (k.x + k.y * t + k.z * p) + k.w * m * m * (p - t);
+        du[o] = dp * p * (1.f - p);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sigmoid(const float* __restrict__ u, long long n, float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = sigmoidf(u[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdamW (torch.optim.AdamW single-tensor formula, unet.py:457): decoupled weight decay, then Adam.
+// Consumes and clears the fp64 gradient accumulator; optionally exports the fp32 gradient.
+// ---------------------------------------------------------------------------------------------
+struct Hyper {
+    double lr, beta1, beta2, eps, wd;
+};
+
+__global__ void __launch_bounds__(256) k_adamw(long long n, float* __restrict__ p, double* __restrict__ gacc,
+                                               float* __restrict__ m, float* __restrict__ v, Hyper h, int step) {
+    const double bc1 = 1.0 - pow(h.beta1, (double)step);
+    const double bc2 = 1.0 - pow(h.beta2, (double)step);
+    const float step_size = (float)(h.lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float decay = (float)(1.0 - h.lr * h.wd);
+    const float b1 = (float)h.beta1, b2 = (float)h.beta2, eps = (float)h.eps;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float g = (float)gacc[i];
+        gacc[i] = 0.0;
+        float w = p[i] * decay;
+        const float mi = m[i] + (g - m[i]) * (1.f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = fmaf(g * g, 1.f - b2, v[i] * b2);        // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        w -= step_size * (mi / denom);
+        p[i] = w;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_acc_to_f32(long long n, const double* __restrict__ gacc, float* __restrict__ g32,
+                                                    double scale) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        g32[i] = (float)(gacc[i] * scale);
+}
+
+}  // namespace unet

@@ -1,0 +1,210 @@
+"""UnetEngine — Python owner of one libcae_hip UNET engine (include/cae_unet.h) and of its device memory.
+
+As in engine.py, torch is a container: flat CUDA tensors for the parameter / AdamW / running-statistics
+arenas and the workspace, and a stream.  Every FLOP runs in the HIP kernels."""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CaeError, TensorInfoC, check
+from .engine import _spec_layers, _to_c
+
+TRAIN, TEST = 0, 1
+
+
+class UnetPlan:
+    """geometry-only view (no GPU needed): tensor table, arena and workspace sizes"""
+
+    def __init__(self, spec, fc_size, latent_size, max_batch):
+        self.lib = _lib.load()
+        (enc, dec) = _spec_layers(spec)
+        self.enc_layers, self.dec_layers = enc, dec
+        self.fc_size, self.latent_size, self.max_batch = int(fc_size), int(latent_size), int(max_batch)
+        handle = C.c_void_p()
+        check(self.lib.unet_engine_create(_to_c(enc), len(enc), _to_c(dec), len(dec), self.fc_size, self.latent_size,
+                                          self.max_batch, C.byref(handle)))
+        self.handle = handle
+        self.n_param = int(self.lib.unet_param_count(handle))
+        self.n_buffer = int(self.lib.unet_buffer_count(handle))
+        self.workspace_bytes = int(self.lib.unet_workspace_bytes(handle))
+        self.tensors = OrderedDict()
+        info = TensorInfoC()
+        for i in range(self.lib.unet_tensor_count(handle)):
+            check(self.lib.unet_tensor_info(handle, i, C.byref(info)))
+            shape = tuple(int(info.shape[d]) for d in range(info.ndim))
+            self.tensors[info.name.decode()] = (int(info.arena), int(info.offset), int(info.numel), shape)
+        self.in_shape = tuple(enc[0]["input_dimensions"])
+        self.out_shape = tuple(dec[-1]["output_dimensions"])
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.unet_engine_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class UnetEngine(UnetPlan):
+
+    def __init__(self, spec, fc_size, latent_size, max_batch, device=None, specialised=True):
+        if not torch.cuda.is_available():
+            raise CaeError("cae_tools_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        super().__init__(spec, fc_size, latent_size, max_batch)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.Stream()
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(self.n_param, **f32)
+        self.exp_avg = torch.zeros(self.n_param, **f32)
+        self.exp_avg_sq = torch.zeros(self.n_param, **f32)
+        self.buffers = torch.zeros(max(self.n_buffer, 4), **f32)
+        self.workspace = torch.zeros(self.workspace_bytes + 256, dtype=torch.uint8, device=self.device)
+        ws_ptr = (self.workspace.data_ptr() + 255) // 256 * 256
+        check(self.lib.unet_bind(self.handle, self.params.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                 self.buffers.data_ptr(), ws_ptr, self.workspace_bytes))
+        check(self.lib.unet_set_stream(self.handle, self.stream.cuda_stream))
+        check(self.lib.unet_set_kernel_mode(self.handle, 1 if specialised else 0))
+        torch.cuda.synchronize(self.device)
+        self.num_batches_tracked = 0
+        self.steps = 0
+        self._keep = {}
+        self.loss_slots = int(self.lib.unet_loss_slots(self.handle))
+
+    # ---- parameters ------------------------------------------------------------------------------
+    def view(self, name):
+        (arena, off, numel, shape) = self.tensors[name]
+        return (self.params if arena == 0 else self.buffers)[off:off + numel].view(shape)
+
+    def load_state(self, enc_state, dec_state):
+        """copy reference-format state dicts (encoder.weights / decoder.weights of a UNET) into the arenas"""
+        self.sync()
+        nbt = None
+        for prefix, sd in (("enc/", enc_state), ("dec/", dec_state)):
+            for k, v in sd.items():
+                if k.endswith("num_batches_tracked"):
+                    nbt = int(np.asarray(v)) if nbt is None else nbt
+                    continue
+                name = prefix + k
+                if name not in self.tensors:
+                    raise CaeError(f"unexpected tensor '{k}' for this model geometry")
+                t = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v).to(torch.float32)
+                dst = self.view(name)
+                if tuple(t.shape) != tuple(dst.shape):
+                    raise CaeError(f"shape mismatch for '{k}': {tuple(t.shape)} vs {tuple(dst.shape)}")
+                dst.copy_(t.to(self.device))
+        missing = [n for n in self.tensors if (n[4:] not in (enc_state if n.startswith("enc/") else dec_state))]
+        if missing:
+            raise CaeError(f"state dict is missing {missing[:3]}...")
+        if nbt is not None:
+            self.num_batches_tracked = nbt
+        torch.cuda.synchronize(self.device)
+
+    def export_state(self):
+        """(encoder_state, decoder_state): CPU tensors under the reference's keys, in its state_dict order"""
+        self.sync()
+        enc, dec = OrderedDict(), OrderedDict()
+        for name in self.tensors:
+            side = enc if name.startswith("enc/") else dec
+            side[name[4:]] = self.view(name).detach().cpu().clone()
+            if name.endswith(".running_var"):
+                side[name[4:-len("running_var")] + "num_batches_tracked"] = torch.tensor(self.num_batches_tracked,
+                                                                                         dtype=torch.int64)
+        return enc, dec
+
+    def reset_optimizer(self):
+        self.sync()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.steps = 0
+        check(self.lib.unet_set_step(self.handle, 0))
+        torch.cuda.synchronize(self.device)
+
+    def set_hyper(self, lr=1e-3, weight_decay=1e-5, dropout_rate=0.1, lambda_pearson=1.0, seed=0, betas=(0.9, 0.999), eps=1e-8):
+        check(self.lib.unet_set_hyper(self.handle, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                      float(weight_decay), float(dropout_rate), float(lambda_pearson), int(seed) & 0xFFFFFFFF))
+
+    def set_step(self, step):
+        self.steps = int(step)
+        check(self.lib.unet_set_step(self.handle, self.steps))
+
+    # ---- data ---------------------------------------------------------------------------------------
+    def set_dataset(self, which, x, t=None, mask=None):
+        """x (N,Cin,H,W), t (N,Cout,H,W), mask (N,1|Cout,H,W) or None: fp32 CUDA tensors kept alive here"""
+        def prep(a):
+            return None if a is None else a.to(device=self.device, dtype=torch.float32).contiguous()
+        (x, t, mask) = (prep(x), prep(t), prep(mask))
+        if tuple(x.shape[1:]) != self.in_shape or (t is not None and tuple(t.shape[1:]) != self.out_shape):
+            raise CaeError(f"data set shapes {tuple(x.shape)} / {None if t is None else tuple(t.shape)} do not match "
+                           f"the model ({self.in_shape} -> {self.out_shape})")
+        if mask is not None and (mask.shape[0] != x.shape[0] or tuple(mask.shape[2:]) != self.out_shape[1:]):
+            raise CaeError(f"mask shape {tuple(mask.shape)} does not match the output {self.out_shape}")
+        self._keep[which] = (x, t, mask)
+        check(self.lib.unet_set_dataset(self.handle, which, x.data_ptr(), None if t is None else t.data_ptr(),
+                                        None if mask is None else mask.data_ptr(), 0 if mask is None else int(mask.shape[1]),
+                                        int(x.shape[0])))
+
+    def upload_perm(self, perm):
+        return torch.as_tensor(np.asarray(perm), dtype=torch.int32).to(self.device)
+
+    # ---- steps --------------------------------------------------------------------------------------
+    def train_step(self, which, perm, start, batch, slot=0):
+        check(self.lib.unet_train_step(self.handle, which, None if perm is None else perm.data_ptr(), int(start), int(batch),
+                                       int(slot)))
+        self.steps += 1
+        self.num_batches_tracked += 1
+
+    def forward_backward(self, which, perm, start, batch, slot=0):
+        """loss gradient as a flat fp32 CUDA tensor (parameter-arena layout); BatchNorm running stats advance"""
+        grads = torch.empty(self.n_param, dtype=torch.float32, device=self.device)
+        check(self.lib.unet_forward_backward(self.handle, which, None if perm is None else perm.data_ptr(), int(start),
+                                             int(batch), int(slot), grads.data_ptr()))
+        self.num_batches_tracked += 1
+        self.sync()
+        return grads
+
+    def eval_step(self, which, perm, start, batch, slot=0):
+        check(self.lib.unet_eval_step(self.handle, which, None if perm is None else perm.data_ptr(), int(start), int(batch),
+                                      int(slot)))
+
+    def run_batches(self, which, perm, n, batch_size, train):
+        """one epoch over n samples in batches of batch_size (last one partial): [(mse, pearson loss)] per batch"""
+        out = []
+        starts = list(range(0, n, batch_size))
+        for lo in range(0, len(starts), self.loss_slots):
+            chunk = starts[lo:lo + self.loss_slots]
+            for (slot, start) in enumerate(chunk):
+                size = min(batch_size, n - start)
+                (self.train_step if train else self.eval_step)(which, perm, start, size, slot)
+            out.extend(self.read_losses(0, len(chunk)))
+        return out
+
+    def read_losses(self, first, count):
+        buf = (C.c_double * (2 * count))()
+        check(self.lib.unet_read_losses(self.handle, int(first), int(count), buf))
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(count)]
+
+    def score(self, x):
+        """eval-mode forward of (N,Cin,H,W) in chunks of max_batch -> (N,Cout,H,W) fp32 CUDA tensor"""
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty((x.shape[0],) + self.out_shape, dtype=torch.float32, device=self.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        for lo in range(0, x.shape[0], self.max_batch):
+            hi = min(x.shape[0], lo + self.max_batch)
+            check(self.lib.unet_score(self.handle, x[lo:hi].data_ptr(), hi - lo, out[lo:hi].data_ptr()))
+        self.sync()
+        return out
+
+    def sync(self):
+        check(self.lib.unet_sync(self.handle))
+
+    def debug_read(self, what, shape):
+        out = np.empty(shape, dtype=np.float32)
+        check(self.lib.unet_debug_read(self.handle, what.encode(), out.ctypes.data, out.size))
+        return out

@@ -1,0 +1,156 @@
+"""UNET HIP path (include/cae_unet.h) against the reference-generated vectors (tests/golden/unet_*.npz) and, for
+train-mode dropout (whose masks are a hash both sides share), against the pinned CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from unet_helpers import TRAIN_CASES, UNET_CASES, UnetCase, unet_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(case, max_batch=None, dropout=None, specialised=True, seed=0):
+    from cae_tools_amd.unet_engine import UnetEngine
+    m = case.meta
+    eng = UnetEngine(m["spec"], m["fc"], m["latent"], max_batch or m["batch"], device="cuda:0", specialised=specialised)
+    eng.load_state(case.state("init", "enc"), case.state("init", "dec"))
+    eng.set_hyper(lr=m["lr"], weight_decay=m["weight_decay"], dropout_rate=m["dropout"] if dropout is None else dropout,
+                  lambda_pearson=m["lambda_pearson"], seed=seed)
+    return eng
+
+
+def _grad_dict(eng, flat):
+    flat = flat.cpu()
+    return {n: flat[off:off + numel].view(shape) for n, (arena, off, numel, shape) in eng.tensors.items() if arena == 0}
+
+
+def _feeds_batchnorm(key):
+    """biases added right before a BatchNorm: their exact gradient is 0; both sides hold rounding noise (~1e-8)"""
+    return key.endswith(".bias") and (("encoder_cnn." in key and int(key.split(".")[1]) % 4 == 0)
+                                      or "encoder_lin.0." in key or "decoder_lin.0." in key)
+
+
+def _close(got, want, rel, floor, msg=""):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    tol = rel * max(np.abs(want).max(), floor)
+    err = np.abs(got - want).max()
+    assert err <= tol, f"{msg}: max err {err:.3e} > {tol:.3e}"
+
+
+@pytest.mark.parametrize("specialised", [True, False])
+@pytest.mark.parametrize("name", UNET_CASES)
+def test_eval_forward_and_losses(name, specialised):
+    c = UnetCase(name)
+    eng = _engine(c, specialised=specialised)
+    y = eng.score(c.t("x0")).cpu().numpy()
+    np.testing.assert_allclose(y, c.z["eval/y"], rtol=0, atol=5e-6)
+    eng.set_dataset(0, c.t("x0"), c.t("t0"), None if c.meta["mask"] == "ones" else c.t("m0"))
+    eng.eval_step(0, None, 0, c.z["x0"].shape[0], slot=3)
+    (mse, pl) = eng.read_losses(3, 1)[0]
+    np.testing.assert_allclose([mse, pl], c.z["eval/losses"], rtol=2e-5)
+
+
+@pytest.mark.parametrize("specialised", [True, False])
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_train_forward_backward(name, specialised):
+    c = UnetCase(name)
+    eng = _engine(c, specialised=specialised)
+    (x, t, m) = c.step_batch(0)
+    eng.set_dataset(0, x, t, None if c.meta["mask"] == "ones" else m)
+    g = _grad_dict(eng, eng.forward_backward(0, None, 0, x.shape[0], slot=0))
+    (mse, pl) = eng.read_losses(0, 1)[0]
+    np.testing.assert_allclose([mse, pl], c.z["step_losses"][0], rtol=2e-5)
+    for name_, gv in g.items():
+        want = c.z["grad/" + name_]
+        if _feeds_batchnorm(name_):
+            assert np.abs(gv.numpy()).max() < 2e-5 and np.abs(want).max() < 2e-5, name_
+            continue
+        # fp32 gradients of a 10-layer net: agreement to ~1e-3 of the tensor's largest entry
+        _close(gv.numpy(), want, 2e-3, 1e-6, name_)
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_adamw_steps(name):
+    c = UnetCase(name)
+    eng = _engine(c)
+    nsteps = c.meta["nsteps"]
+    losses = []
+    for i in range(nsteps):
+        (x, t, m) = c.step_batch(i)
+        eng.set_dataset(0, x, t, None if c.meta["mask"] == "ones" else m)
+        eng.train_step(0, None, 0, x.shape[0], slot=i)
+        if i == 0:
+            (enc, dec) = eng.export_state()
+            for (pre, sd) in (("enc/", enc), ("dec/", dec)):
+                for k, v in sd.items():
+                    want = c.z["step1/" + pre + k]
+                    if k.endswith("num_batches_tracked"):
+                        assert int(v) == int(want)
+                    elif _feeds_batchnorm(pre + k):
+                        assert np.abs(v.numpy() - want).max() <= 2.1 * c.meta["lr"], k   # Adam turns noise into +-lr
+                    else:
+                        # the first AdamW step is lr * g / (|g| + eps) = lr * sign(g) wherever |g| >> eps = 1e-8: entries
+                        # whose reference gradient is significant must agree closely, the rest may differ by up to 2*lr
+                        diff = np.abs(v.numpy() - want)
+                        assert diff.max() <= 2.1 * c.meta["lr"], k
+                        if ("grad/" + pre + k) in c.z:
+                            sig = np.abs(c.z["grad/" + pre + k]) > 1e-5
+                            assert (diff[sig] <= 2e-5 + 1e-4 * np.abs(want).max()).all(), k
+                        else:   # running statistics
+                            assert diff.max() <= 1e-5 + 1e-4 * np.abs(want).max(), k
+    got = eng.read_losses(0, nsteps)
+    np.testing.assert_allclose(np.array(got), c.z["step_losses"], rtol=5e-3)
+
+
+def test_train_dropout_matches_oracle_hash_masks():
+    """dropout 0.25 in train mode: the engine and the oracle draw the same hash masks"""
+    c = UnetCase("u_k4_b3")
+    eng = _engine(c, dropout=0.25, seed=77)
+    eng.set_step(5)
+    o = unet_oracle(c, dropout_rate=0.25, seed=77)
+    o.step_count = 5
+    (x, t, m) = c.step_batch(0)
+    eng.set_dataset(0, x, t, m)
+    g = _grad_dict(eng, eng.forward_backward(0, None, 0, x.shape[0], slot=1))
+    (mse, pl, _) = o.loss_and_grads(x, t, m)
+    np.testing.assert_allclose(eng.read_losses(1, 1)[0], [mse, pl], rtol=2e-5)
+    for k, want in o.grads().items():
+        if _feeds_batchnorm(k):
+            assert np.abs(g[k].numpy()).max() < 2e-5, k
+            continue
+        _close(g[k].numpy(), want.numpy(), 2e-3, 1e-6, k)
+
+
+def test_permutation_and_partial_batches():
+    """samples are gathered through the permutation; a smaller batch than max_batch reuses the workspace"""
+    c = UnetCase("u_rect_b4")
+    eng = _engine(c, max_batch=4)
+    (x, t, m) = c.step_batch(0)
+    eng.set_dataset(0, x, t, m)
+    perm = eng.upload_perm([2, 0, 3, 1])
+    eng.eval_step(0, perm, 1, 3, slot=0)       # samples 0, 3, 1
+    o = unet_oracle(c)
+    idx = [0, 3, 1]
+    want = o.eval_losses(x[idx], t[idx], m[idx])
+    np.testing.assert_allclose(eng.read_losses(0, 1)[0], want, rtol=2e-5)
+
+
+def test_errors():
+    from cae_tools_amd._lib import CaeError
+    from cae_tools_amd.unet_engine import UnetEngine, UnetPlan
+    c = UnetCase("u_k4_b3")
+    spec = c.meta["spec"]
+    with pytest.raises(CaeError, match="one layer per encoder layer"):
+        UnetPlan({"input_layers": spec["input_layers"], "output_layers": spec["output_layers"][:2]}, 8, 4, 2)
+    bad = {"input_layers": spec["input_layers"], "output_layers": [dict(l) for l in spec["output_layers"]]}
+    bad["output_layers"][1]["input_dimensions"] = [16, 4, 4]
+    with pytest.raises(CaeError, match="2 x out_channels"):
+        UnetPlan(bad, 8, 4, 2)
+    eng = _engine(c)
+    with pytest.raises(CaeError, match="not set"):
+        eng.eval_step(0, None, 0, 2)
+    eng.set_dataset(0, c.t("x0"), c.t("t0"), c.t("m0"))
+    with pytest.raises(CaeError, match="outside the data set"):
+        eng.eval_step(0, None, 2, 3)
+    with pytest.raises(CaeError, match="outside 1"):
+        eng.eval_step(0, None, 0, 9)
