@@ -9,6 +9,7 @@ import numpy as np
 
 from ..data.arrays import DataArray, open_mfdataset
 from ..models.conv_ae_model import ConvAEModel
+from ..models.unet import UNET
 
 
 def build_parser():
@@ -27,9 +28,9 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     with open(os.path.join(args.model_folder, "parameters.json")) as f:
         parameters = json.loads(f.read())
-    if parameters["type"] != "ConvAEModel":
-        raise SystemExit(f"cae_tools_amd implements ConvAEModel only; model folder holds a {parameters['type']}")
-    mt = ConvAEModel()
+    if parameters["type"] not in ("ConvAEModel", "UNET"):
+        raise SystemExit(f"cae_tools_amd implements ConvAEModel and UNET; model folder holds a {parameters['type']}")
+    mt = ConvAEModel() if parameters["type"] == "ConvAEModel" else UNET()
     mt.load(args.model_folder)
 
     model_names = mt.get_input_variable_names()

@@ -13,6 +13,7 @@ import numpy as np
 
 from ..data.arrays import DataArray, open_mfdataset
 from ..models.conv_ae_model import ConvAEModel
+from ..models.unet import UNET
 from ..models.model_sizer import ModelSpec
 
 
@@ -83,18 +84,25 @@ def main(argv=None):
     if args.continue_training:
         with open(os.path.join(args.model_folder, "parameters.json")) as f:
             parameters = json.loads(f.read())
-        if parameters["type"] != "ConvAEModel":
-            raise SystemExit(f"cae_tools_amd implements ConvAEModel only; model folder holds a {parameters['type']}")
-        mt = ConvAEModel()
+        if parameters["type"] not in ("ConvAEModel", "UNET"):
+            raise SystemExit(f"cae_tools_amd implements ConvAEModel and UNET; model folder holds a {parameters['type']}")
+        mt = ConvAEModel() if parameters["type"] == "ConvAEModel" else UNET()
         mt.load(args.model_folder)
         mt.nr_epochs = args.nr_epochs
         mt.lr = args.learning_rate
         mt.batch_size = args.batch_size
     else:
-        if args.method != "conv":
-            raise SystemExit(f"--method {args.method}: cae_tools_amd implements the 'conv' (ConvAEModel) path only")
-        mt = ConvAEModel(fc_size=args.fc_size, encoded_dim_size=args.latent_size, nr_epochs=args.nr_epochs,
-                         batch_size=args.batch_size, lr=args.learning_rate)
+        if args.method == "conv":
+            mt = ConvAEModel(fc_size=args.fc_size, encoded_dim_size=args.latent_size, nr_epochs=args.nr_epochs,
+                             batch_size=args.batch_size, lr=args.learning_rate)
+        elif args.method == "unet":     # cli/train_cae.py:131-135
+            mt = UNET(fc_size=args.fc_size, encoded_dim_size=args.latent_size, nr_epochs=args.nr_epochs,
+                      batch_size=args.batch_size, lr=args.learning_rate, lambda_l1=args.lambda_l1,
+                      lambda_pearson=args.lambda_pearson, database_path=args.database_path,
+                      weight_decay=args.weight_decay, dropout_rate=args.dropout_rate)
+        else:
+            raise SystemExit(f"--method {args.method}: cae_tools_amd implements the 'conv' (ConvAEModel) and 'unet' "
+                             "(UNET) paths only")
         if args.model_id:
             mt.set_model_id(args.model_id)
         if args.layer_definitions_path:

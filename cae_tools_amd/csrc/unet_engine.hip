@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -95,8 +96,8 @@ struct unet_engine {
     int64_t n_params = 0, n_buffers = 0;
     // workspace
     int64_t ws_bytes = 0;
-    int64_t off_gacc = 0, off_dsum = 0, n_dsum = 0, off_losses = 0, off_ls = 0, off_f32 = 0;
-    int64_t xb = 0, y = 0, coef = 0;
+    int64_t off_gacc = 0, off_dsum = 0, n_dsum = 0, off_losses = 0, off_ls = 0, off_f32 = 0, off_gscratch = 0;
+    int64_t xb = 0, y = 0, coef = 0, scratch = 0;
     char* ws = nullptr;
     float *params = nullptr, *m = nullptr, *v = nullptr, *buffers = nullptr;
     hipStream_t stream = nullptr;
@@ -175,7 +176,7 @@ void conv_down(unet_engine* e, const Geom& g, const float* L, const float* w, co
 
 void conv_up(unet_engine* e, const Geom& g, const float* S, const float* w, const float* bias, float* L) {
     if (e->specialised && mfma_up_eligible(g)) {
-        mfma_up_launch(g, S, w, bias, L, e->stream);
+        mfma_up_launch(g, S, w, bias, L, e->f(e->scratch), e->stream);
         return;
     }
     const long long total = (long long)g.B * g.Cl * g.Hl * g.Wl;
@@ -232,11 +233,27 @@ void bn_backward(unet_engine* e, const Bn& bn, const float* gA, long long gAbs, 
 }
 
 void lin_fwd(unet_engine* e, const Fc& L, int B, const float* in, float* out) {
+    if (e->specialised) {   // out[b][o] = bias[o] + sum_i in[b][i] W[o][i]
+        GemmDesc d{L.nout, B, L.nin, e->P(L.w), L.nin, 1, in, 1, L.nin, e->P(L.b), out, nullptr, 1, L.nout, 0};
+        gemm_launch(d, reinterpret_cast<double*>(e->ws + e->off_gscratch), e->stream);
+        return;
+    }
     hipLaunchKernelGGL(k_lin_fwd, dim3(L.nout, (B + 7) / 8), dim3(256), 0, e->stream, B, L.nin, L.nout, in, e->P(L.w),
                        e->P(L.b), out);
 }
 
 void lin_bwd(unet_engine* e, const Fc& L, int B, const float* in, const float* gout, float* gin) {
+    if (e->specialised) {
+        // dW[o][i] += sum_b gout[b][o] in[b][i];  db[o] += sum_b gout[b][o];  gin[b][i] = sum_o gout[b][o] W[o][i]
+        GemmDesc w{L.nout, L.nin, B, gout, 1, L.nout, in, L.nin, 1, nullptr, nullptr, e->gacc(L.w), L.nin, 1, 2};
+        gemm_launch(w, nullptr, e->stream);
+        hipLaunchKernelGGL(k_col_sums, dim3((L.nout + 255) / 256), dim3(256), 0, e->stream, B, L.nout, gout, e->gacc(L.b));
+        if (gin) {
+            GemmDesc d{L.nin, B, L.nout, e->P(L.w), 1, L.nin, gout, 1, L.nout, nullptr, gin, nullptr, 1, L.nin, 0};
+            gemm_launch(d, reinterpret_cast<double*>(e->ws + e->off_gscratch), e->stream);
+        }
+        return;
+    }
     hipLaunchKernelGGL(k_lin_wgrad, dim3(blocks_for((long long)L.nout * L.nin, 65536)), dim3(256), 0, e->stream, B, L.nin,
                        L.nout, gout, in, e->gacc(L.w), e->gacc(L.b));
     if (gin)
@@ -585,6 +602,10 @@ int unet_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spe
         }
     }
     e->coef = F32(4 * B * e->out_c);
+    int64_t wmax = 0;
+    for (auto& L : e->enc) wmax = std::max<int64_t>(wmax, (int64_t)L.g.Cs * L.g.Cl * L.g.kh * L.g.kw);
+    for (auto& L : e->dec) wmax = std::max<int64_t>(wmax, (int64_t)L.g.Cs * L.g.Cl * L.g.kh * L.g.kw);
+    e->scratch = F32(wmax);   // repacked weights of the layer being launched (kernels_unet_mfma.h)
     int64_t off = 0;
     auto bytes = [&](int64_t n) {
         const int64_t o = off;
@@ -595,6 +616,9 @@ int unet_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spe
     e->off_dsum = bytes(nd * 8);
     e->off_losses = bytes((int64_t)kLossSlots * 2 * 8);
     e->off_ls = bytes(B * e->out_c * 8 * 8);
+    int64_t gs = 0;   // split-K scratch of the Linear GEMMs: rows x batch doubles, kept zero between uses
+    for (int k = 0; k < 4; k++) gs = std::max<int64_t>(gs, (int64_t)std::max(e->fc[k].nin, e->fc[k].nout) * B);
+    e->off_gscratch = bytes(gs * 8);
     e->off_f32 = bytes(nf * 4);
     e->ws_bytes = off;
     *out = e;

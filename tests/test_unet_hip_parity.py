@@ -154,3 +154,40 @@ def test_errors():
         eng.eval_step(0, None, 2, 3)
     with pytest.raises(CaeError, match="outside 1"):
         eng.eval_step(0, None, 0, 9)
+
+
+def test_mfma_path_at_medium_size_against_oracle_and_generic_kernels():
+    """wide layers (32 / 64 / 96 channels: full tiles, a 64-row tile and a partly filled 128-row tile), odd batch,
+    64x64 maps, dropout on: MFMA convolutions + GEMM Linear layers against the CPU oracle and the generic kernels"""
+    from cae_tools_amd.models.unet import Decoder, Encoder, unet_layer_spec
+    from cae_tools_amd.unet_engine import UnetEngine
+    from oracle import unet_oracle as uo
+    spec = unet_layer_spec(3, 3, (64, 64), [32, 64, 96])
+    (fc, latent, B) = (24, 6, 5)
+    torch.manual_seed(123)
+    enc = Encoder(spec.get_input_layers(), latent, fc)
+    dec = Decoder(spec.get_output_layers(), latent, fc)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand((B, 3, 64, 64), generator=g)
+    t = torch.rand((B, 3, 64, 64), generator=g)
+    m = (torch.rand((B, 1, 64, 64), generator=g) < 0.85).float()
+    o = uo.UnetOracle(spec.save(), enc.state_dict(), dec.state_dict(), dropout_rate=0.1, seed=4)
+    o.step_count = 2
+    (mse, pl, _) = o.loss_and_grads(x, t, m)
+    want = o.grads()
+    res = {}
+    for specialised in (True, False):
+        eng = UnetEngine(spec, fc, latent, B, device="cuda:0", specialised=specialised)
+        eng.load_state(enc.state_dict(), dec.state_dict())
+        eng.set_hyper(dropout_rate=0.1, seed=4)
+        eng.set_step(2)
+        eng.set_dataset(0, x, t, m)
+        res[specialised] = (_grad_dict(eng, eng.forward_backward(0, None, 0, B, slot=0)), eng.read_losses(0, 1)[0],
+                            eng.score(x).cpu().numpy())
+        np.testing.assert_allclose(res[specialised][1], [mse, pl], rtol=3e-5)
+        for k, w in want.items():
+            if _feeds_batchnorm(k):
+                continue
+            _close(res[specialised][0][k].numpy(), w.numpy(), 6e-3, 1e-6, f"{k} (specialised={specialised})")
+    np.testing.assert_allclose(res[True][2], res[False][2], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(res[True][2], o.eval_forward(x).numpy(), rtol=0, atol=2e-5)
