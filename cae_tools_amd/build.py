@@ -24,6 +24,7 @@ SOURCES = {
     "unet_engine.hip": ["kernels_unet.h", "kernels_unet_mfma.h", "cae_unet.h", "cae_hip.h"],
 }
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-cuda-compat", "-Wno-pass-failed"]
+FLAGS += os.environ.get("CAE_HIPCC_FLAGS", "").split()     # tuning experiments: e.g. CAE_HIPCC_FLAGS=-DIG_KCW=32
 
 
 def _hipcc():

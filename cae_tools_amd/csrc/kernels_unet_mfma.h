@@ -35,14 +35,15 @@ struct OpDown {
     const float* __restrict__ w;
     const float* __restrict__ bias;
     float* __restrict__ S;
+    int nsplit, ksplit;   // K slices (blockIdx.z) of ksplit chunks; nsplit > 1: S is pre-zeroed and added to atomically
     struct Ctx {
         long long xbase[WM];
         unsigned vmask[WM];
     };
     __device__ int rows() const { return g.Cs; }
     __device__ long long cols() const { return (long long)g.B * g.Hs * g.Ws; }
-    __device__ int k_begin(int) const { return 0; }
-    __device__ int k_end(int) const { return g.Cl * 16; }
+    __device__ int k_begin(int z) const { return z * ksplit * IG_KC; }
+    __device__ int k_end(int z) const { return min(g.Cl * 16, (z + 1) * ksplit * IG_KC); }
     __device__ void init(Ctx& c, int tid, long long m0, int) const {
         const int HW = g.Hs * g.Ws;
 #pragma unroll
@@ -91,11 +92,13 @@ struct OpDown {
 #pragma unroll
             for (int i = 0; i < 8; i++) Xb[((tid >> 7) + 2 * i) * XS + (tid & 127) + 128 * j] = xr[j * 8 + i];
     }
-    __device__ void store(int n, long long m, float v, int) const {
+    __device__ void store(int n, long long m, float v, int z) const {
         if (n >= g.Cs || m >= cols()) return;
         const int HW = g.Hs * g.Ws;
         const long long b = m / HW, p = m - b * HW;
-        S[(b * g.Cs + n) * HW + p] = v + (bias ? bias[n] : 0.f);
+        if (z == 0 && bias) v += bias[n];
+        if (nsplit > 1) atomicAdd(&S[(b * g.Cs + n) * HW + p], v);
+        else S[(b * g.Cs + n) * HW + p] = v;
     }
 };
 
@@ -446,8 +449,18 @@ inline void igemm_dispatch(int rows, long long cols, int zdim, hipStream_t s, Fi
 }
 
 inline void mfma_down_launch(const Geom& g, const float* L, const float* w, const float* bias, float* S, hipStream_t s) {
-    igemm_dispatch<OpDown>(g.Cs, (long long)g.B * g.Hs * g.Ws, 1, s, [&](auto& op) {
-        op.g = g, op.L = L, op.w = w, op.bias = bias, op.S = S;
+    // few output tiles and a long K (the deep layers): slice K over blockIdx.z so that every CU has work
+    const int rows = g.Cs;
+    const long long cols = (long long)g.B * g.Hs * g.Ws;
+    const int TN = rows <= 32 ? 32 : rows <= 64 ? 64 : 128, TM = rows <= 32 ? 512 : rows <= 64 ? 256 : 128;
+    const long long tiles = ((rows + TN - 1) / TN) * ((cols + TM - 1) / TM);
+    const int chunks = g.Cl;   // K / 16
+    int nsplit = 1;
+    while (tiles * nsplit < 384 && chunks / (nsplit * 2) >= 16 && nsplit < 8) nsplit *= 2;
+    const int per = (chunks + nsplit - 1) / nsplit;
+    if (nsplit > 1) (void)hipMemsetAsync(S, 0, (size_t)cols * rows * sizeof(float), s);
+    igemm_dispatch<OpDown>(rows, cols, nsplit, s, [&](auto& op) {
+        op.g = g, op.L = L, op.w = w, op.bias = bias, op.S = S, op.nsplit = nsplit, op.ksplit = per;
     });
 }
 

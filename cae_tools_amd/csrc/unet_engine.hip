@@ -411,7 +411,8 @@ int backward(unet_engine* e, const float* x, int B) {
         const float* in = i == 0 ? x : (make_drop(e, SITE_ENC_CONV + i - 1, true).on ? e->f(e->enc[i - 1].a) : e->f(e->enc[i - 1].s));
         // Conv2d: S = output, L = input
         conv_wgrad(e, g, e->f(L.gz), in, e->gacc(L.w));
-        chan_sums(e, e->f(L.gz), (long long)C * HW, B, C, HW, e->gacc(L.b), 1, 0);
+        // no bias gradient: this bias is added right before a BatchNorm, whose backward makes every channel of dz sum
+        // to zero (the reference's autograd returns rounding noise of ~1e-8 here)
         if (i > 0) {
             conv_up(e, g, e->f(L.gz), e->P(L.w), nullptr, e->f(e->enc[i - 1].ga));
             gin = e->f(e->enc[i - 1].ga);
