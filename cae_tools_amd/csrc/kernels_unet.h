@@ -153,6 +153,64 @@ __global__ void __launch_bounds__(256) k_wgrad(Geom g, const float* __restrict__
     if (threadIdx.x == 0 && t != 0.0) atomicAdd(&acc[blockIdx.x], t);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 4x4 / stride 2 / pad 1 transposed convolution with a handful of output channels (the last decoder layer: Cl = 3).
+// A GEMM tile would be 3 rows tall; this is a streaming problem instead: one thread per input position (b,q,r) forms
+// the 2x2 output quad of every output channel from the 3x3 neighbourhood of each input channel; the weights of the
+// channel in flight are wave-uniform (scalar loads, SGPR operands).  grid-stride over B*Hs*Ws
+// ---------------------------------------------------------------------------------------------
+template <int CL>
+__global__ void __launch_bounds__(256) k_up_thin(Geom g, const float* __restrict__ S, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, float* __restrict__ L) {
+    const int HW = g.Hs * g.Ws;
+    const long long total = (long long)g.B * HW;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int b = (int)(idx / HW), p = (int)(idx - (long long)b * HW);
+        const int q = p / g.Ws, r = p - q * g.Ws;
+        float acc[CL][2][2];
+#pragma unroll
+        for (int cl = 0; cl < CL; cl++) {
+            const float bv = bias ? bias[cl] : 0.f;
+            acc[cl][0][0] = acc[cl][0][1] = acc[cl][1][0] = acc[cl][1][1] = bv;
+        }
+        const bool up = q > 0, dn = q + 1 < g.Hs, lf = r > 0, rt = r + 1 < g.Ws;
+        const float* sp = S + (size_t)b * g.Cs * HW + p;
+        for (int cs = 0; cs < g.Cs; cs++, sp += HW) {
+            float v[3][3];
+            v[0][0] = up && lf ? sp[-g.Ws - 1] : 0.f;
+            v[0][1] = up ? sp[-g.Ws] : 0.f;
+            v[0][2] = up && rt ? sp[-g.Ws + 1] : 0.f;
+            v[1][0] = lf ? sp[-1] : 0.f;
+            v[1][1] = sp[0];
+            v[1][2] = rt ? sp[1] : 0.f;
+            v[2][0] = dn && lf ? sp[g.Ws - 1] : 0.f;
+            v[2][1] = dn ? sp[g.Ws] : 0.f;
+            v[2][2] = dn && rt ? sp[g.Ws + 1] : 0.f;
+            const float* wp = w + (size_t)cs * CL * 16;
+#pragma unroll
+            for (int cl = 0; cl < CL; cl++)
+#pragma unroll
+                for (int py = 0; py < 2; py++)
+#pragma unroll
+                    for (int px = 0; px < 2; px++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++)
+#pragma unroll
+                            for (int i = 0; i < 2; i++)   // output (2q+py, 2r+px) sees S[q+py-j][r+px-i] through w[1-py+2j][1-px+2i]
+                                acc[cl][py][px] = fmaf(v[1 + py - j][1 + px - i], wp[cl * 16 + (1 - py + 2 * j) * 4 + (1 - px + 2 * i)],
+                                                       acc[cl][py][px]);
+        }
+#pragma unroll
+        for (int cl = 0; cl < CL; cl++)
+#pragma unroll
+            for (int py = 0; py < 2; py++) {
+                float2* dst = reinterpret_cast<float2*>(L + (((size_t)b * CL + cl) * g.Hl + 2 * q + py) * g.Wl + 2 * r);
+                *dst = make_float2(acc[cl][py][0], acc[cl][py][1]);
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-channel reductions and BatchNorm (2-d: (B,C,HW); 1-d: HW = 1)
 // ---------------------------------------------------------------------------------------------

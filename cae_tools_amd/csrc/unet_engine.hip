@@ -175,6 +175,16 @@ void conv_down(unet_engine* e, const Geom& g, const float* L, const float* w, co
 }
 
 void conv_up(unet_engine* e, const Geom& g, const float* S, const float* w, const float* bias, float* L) {
+    if (e->specialised && mfma_geom(g) && g.Cl <= 4) {   // a handful of output channels: streaming kernel, not a GEMM
+        const int blocks = blocks_for((long long)g.B * g.Hs * g.Ws, 65536);
+        switch (g.Cl) {
+            case 1: hipLaunchKernelGGL(k_up_thin<1>, dim3(blocks), dim3(256), 0, e->stream, g, S, w, bias, L); break;
+            case 2: hipLaunchKernelGGL(k_up_thin<2>, dim3(blocks), dim3(256), 0, e->stream, g, S, w, bias, L); break;
+            case 3: hipLaunchKernelGGL(k_up_thin<3>, dim3(blocks), dim3(256), 0, e->stream, g, S, w, bias, L); break;
+            default: hipLaunchKernelGGL(k_up_thin<4>, dim3(blocks), dim3(256), 0, e->stream, g, S, w, bias, L); break;
+        }
+        return;
+    }
     if (e->specialised && mfma_up_eligible(g)) {
         mfma_up_launch(g, S, w, bias, L, e->f(e->scratch), e->stream);
         return;
