@@ -225,7 +225,7 @@ def main():
             for (name, layer, avg, nbytes, share) in table:
                 print(f"{name:28s} L{layer:<2d} {avg:9.2f} us  {nbytes / 1e6:9.2f} MB  {nbytes / avg / 1e3:8.1f} GB/s"
                       f"  {100 * share:5.1f}%", file=sys.stderr)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             result["cpu_baseline"] = cpu_baseline(spec, enc, dec)
     barrier()
     if rank == 0:
