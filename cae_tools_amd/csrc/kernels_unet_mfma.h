@@ -92,13 +92,19 @@ struct OpDown {
 #pragma unroll
             for (int i = 0; i < 8; i++) Xb[((tid >> 7) + 2 * i) * XS + (tid & 127) + 128 * j] = xr[j * 8 + i];
     }
-    __device__ void store(int n, long long m, float v, int z) const {
-        if (n >= g.Cs || m >= cols()) return;
+    // the column (pixel) part of an output address, once per result column; -1: outside
+    __device__ long long col(long long m, int) const {
+        if (m >= cols()) return -1;
         const int HW = g.Hs * g.Ws;
-        const long long b = m / HW, p = m - b * HW;
+        const long long b = m / HW;
+        return b * g.Cs * HW + (m - b * HW);
+    }
+    __device__ void store(long long cb, int n, float v, int z) const {
+        if (n >= g.Cs || cb < 0) return;
+        float* dst = S + cb + (long long)n * g.Hs * g.Ws;
         if (z == 0 && bias) v += bias[n];
-        if (nsplit > 1) atomicAdd(&S[(b * g.Cs + n) * HW + p], v);
-        else S[(b * g.Cs + n) * HW + p] = v;
+        if (nsplit > 1) atomicAdd(dst, v);
+        else *dst = v;
     }
 };
 
@@ -180,13 +186,17 @@ struct OpUp {
 #pragma unroll
             for (int i = 0; i < 8; i++) Xb[((tid >> 7) + 2 * i) * XS + (tid & 127) + 128 * j] = xr[j * 8 + i];
     }
-    __device__ void store(int n, long long m, float v, int z) const {
-        if (n >= g.Cl || m >= cols()) return;
+    __device__ long long col(long long m, int z) const {
+        if (m >= cols()) return -1;
         const int HW = g.Hs * g.Ws;
         const long long b = m / HW;
         const int p = (int)(m - b * HW);
         const int q = p / g.Ws, r = p - q * g.Ws;
-        L[((b * g.Cl + n) * g.Hl + 2 * q + (z >> 1)) * g.Wl + 2 * r + (z & 1)] = v + (bias ? bias[n] : 0.f);
+        return (b * g.Cl * g.Hl + 2 * q + (z >> 1)) * g.Wl + 2 * r + (z & 1);
+    }
+    __device__ void store(long long cb, int n, float v, int) const {
+        if (n >= g.Cl || cb < 0) return;
+        L[cb + (long long)n * g.Hl * g.Wl] = v + (bias ? bias[n] : 0.f);
     }
 };
 
@@ -235,9 +245,10 @@ struct OpWgrad {
 #pragma unroll
         for (int i = 0; i < 8 * WM; i++) Xb[(tid & 15) * XS + (tid >> 4) + 16 * i] = xr[i];
     }
-    __device__ void store(int n, long long m, float v, int) const {
-        if (n >= g.Cs || m >= cols() || v == 0.f) return;
-        atomicAdd(&acc[(size_t)n * g.Cl * 16 + m], (double)v);
+    __device__ long long col(long long m, int) const { return m < cols() ? m : -1; }
+    __device__ void store(long long cb, int n, float v, int) const {
+        if (n >= g.Cs || cb < 0 || v == 0.f) return;
+        atomicAdd(&acc[(size_t)n * g.Cl * 16 + cb], (double)v);
     }
 };
 
@@ -329,8 +340,9 @@ struct OpGemm {
             }
         }
     }
-    __device__ void store(int n, long long m, float v, int) const {
-        if (n >= nrows || m >= ncols) return;
+    __device__ long long col(long long m, int) const { return m < ncols ? m : -1; }
+    __device__ void store(long long m, int n, float v, int) const {
+        if (n >= nrows || m < 0) return;
         if (mode == 0) {
             out[m * o_sm + n * o_sn] = v + (bias ? bias[n] : 0.f);
         } else if (mode == 1) {
@@ -401,11 +413,11 @@ __global__ void __launch_bounds__(256) k_igemm(Op op) {
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const long long m = m0 + wm * 128 + c * 32 + (lane & 31);
+        const long long cb = op.col(m0 + wm * 128 + c * 32 + (lane & 31), z);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            op.store(n, m, acc[c][r], z);
+            op.store(cb, n, acc[c][r], z);
         }
     }
 }
@@ -456,7 +468,10 @@ inline void mfma_down_launch(const Geom& g, const float* L, const float* w, cons
     const long long tiles = ((rows + TN - 1) / TN) * ((cols + TM - 1) / TM);
     const int chunks = g.Cl;   // K / 16
     int nsplit = 1;
-    while (tiles * nsplit < 384 && chunks / (nsplit * 2) >= 16 && nsplit < 8) nsplit *= 2;
+#ifndef IG_SPLIT_TARGET
+#define IG_SPLIT_TARGET 384
+#endif
+    while (tiles * nsplit < IG_SPLIT_TARGET && chunks / (nsplit * 2) >= 8 && nsplit < 8) nsplit *= 2;
     const int per = (chunks + nsplit - 1) / nsplit;
     if (nsplit > 1) (void)hipMemsetAsync(S, 0, (size_t)cols * rows * sizeof(float), s);
     igemm_dispatch<OpDown>(rows, cols, nsplit, s, [&](auto& op) {
