@@ -146,15 +146,23 @@ class UnetEngine(UnetPlan):
         if mask is not None and (mask.shape[0] != x.shape[0] or tuple(mask.shape[2:]) != self.out_shape[1:]):
             raise CaeError(f"mask shape {tuple(mask.shape)} does not match the output {self.out_shape}")
         self._keep[which] = (x, t, mask)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))    # the tensors were produced on torch's stream
         check(self.lib.unet_set_dataset(self.handle, which, x.data_ptr(), None if t is None else t.data_ptr(),
                                         None if mask is None else mask.data_ptr(), 0 if mask is None else int(mask.shape[1]),
                                         int(x.shape[0])))
 
     def upload_perm(self, perm):
-        return torch.as_tensor(np.asarray(perm), dtype=torch.int32).to(self.device)
+        idx = torch.as_tensor(np.asarray(perm), dtype=torch.int32).to(self.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        return idx
 
     # ---- steps --------------------------------------------------------------------------------------
+    def _check_train_batch(self, batch):
+        if int(batch) == 1:   # what nn.BatchNorm1d raises in the reference for a one-sample training batch
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([1, {self.fc_size}])")
+
     def train_step(self, which, perm, start, batch, slot=0):
+        self._check_train_batch(batch)
         check(self.lib.unet_train_step(self.handle, which, None if perm is None else perm.data_ptr(), int(start), int(batch),
                                        int(slot)))
         self.steps += 1
@@ -162,7 +170,9 @@ class UnetEngine(UnetPlan):
 
     def forward_backward(self, which, perm, start, batch, slot=0):
         """loss gradient as a flat fp32 CUDA tensor (parameter-arena layout); BatchNorm running stats advance"""
+        self._check_train_batch(batch)
         grads = torch.empty(self.n_param, dtype=torch.float32, device=self.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         check(self.lib.unet_forward_backward(self.handle, which, None if perm is None else perm.data_ptr(), int(start),
                                              int(batch), int(slot), grads.data_ptr()))
         self.num_batches_tracked += 1

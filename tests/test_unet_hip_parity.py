@@ -154,6 +154,28 @@ def test_errors():
         eng.eval_step(0, None, 2, 3)
     with pytest.raises(CaeError, match="outside 1"):
         eng.eval_step(0, None, 0, 9)
+    # a one-sample TRAINING batch fails in the reference (BatchNorm1d: "Expected more than 1 value per channel")
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        eng.train_step(0, None, 0, 1)
+    eng.eval_step(0, None, 2, 1, slot=5)          # ... while a one-sample eval batch is fine
+    o = unet_oracle(c)
+    np.testing.assert_allclose(eng.read_losses(5, 1)[0], o.eval_losses(c.t("x0")[2:3], c.t("t0")[2:3], c.t("m0")[2:3]), rtol=2e-5)
+
+
+def test_ragged_epoch_matches_oracle_batch_by_batch():
+    """an epoch over 7 samples in batches of 3 (3 + 3 + 1 in eval mode; training drops nothing either: 3 + 3 + ... the
+    reference's DataLoader has drop_last=False): per-batch loss pairs through run_batches"""
+    c = UnetCase("u_rect_b4")
+    (x, t, m) = (torch.cat([c.step_batch(i)[k] for i in range(3)]) for k in range(3))     # 4 + 3 + 4 = 11 samples
+    (x, t, m) = (x[:7], t[:7], m[:7])
+    eng = _engine(c, max_batch=3)
+    eng.set_dataset(1, x, t, m)
+    perm = eng.upload_perm([6, 2, 5, 0, 4, 1, 3])
+    got = eng.run_batches(1, perm, 7, 3, train=False)
+    o = unet_oracle(c)
+    order = [6, 2, 5, 0, 4, 1, 3]
+    want = [o.eval_losses(x[order[i:i + 3]], t[order[i:i + 3]], m[order[i:i + 3]]) for i in (0, 3, 6)]
+    np.testing.assert_allclose(np.array(got), np.array(want), rtol=3e-5)
 
 
 def test_mfma_path_at_medium_size_against_oracle_and_generic_kernels():
