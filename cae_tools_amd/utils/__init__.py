@@ -1,0 +1,1 @@
+"""Experiment bookkeeping: the sqlite ModelDatabase."""
