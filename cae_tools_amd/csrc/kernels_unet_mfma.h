@@ -10,10 +10,16 @@
 //   wgrad                          : n = cs,  m = (cl,ky,kx),     k = (b,y,x) of S,       K = B*Hs*Ws, split over blocks
 //
 // One workgroup = 4 waves = a (32*WN) x (128*WM) tile, WN*WM = 4; each wave owns 32 rows x 128 columns = four
-// 32x32 accumulators (64 VGPRs).  K is walked in chunks of 16 through a double-buffered LDS image
-// (W[16][TN+1], X[16][TM+1]); the gathers of chunk c+1 are in flight while chunk c is multiplied.  Each primitive
-// chooses the thread -> element mapping of its gathers for global-memory coalescing (lanes along x), independent of
-// the MFMA operand layout, which the LDS image provides.
+// 32x32 accumulators (64 AGPRs).  K is walked in chunks of 16 through a double-buffered LDS image in which k is the
+// CONTIGUOUS index: W[n][16+4], X[m][16+4].  The unit of every transfer is a quad = 4 consecutive k of one row:
+//   * global -> registers: one 16-byte load where memory is contiguous along k (weights, activations along x), four
+//     4-byte loads off one base address where it is not (the stride-2 im2col neighbours);
+//   * registers -> LDS: one ds_write_b128 per quad;
+//   * LDS -> MFMA operands: one ds_read_b128 per row gives a lane its operand for FOUR k-steps (lanes 0-31 take
+//     k = 8G+j, lanes 32-63 k = 8G+4+j, j = 0..3), so a chunk is 10 LDS reads per wave for 32 MFMAs.
+// Rows are unpadded (64 bytes); the four quads of row r are stored XOR-swizzled by (r >> 2) & 3, which makes the
+// 16-byte reads of every ds_read_b128 lane group hit 16 different quads (bank-conflict free) without spending LDS
+// on padding (two 32 x 512 tiles fit one CU).  The gathers of chunk c+1 are in flight while chunk c is multiplied.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,13 +29,23 @@ namespace unet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int IG_KC = 16;
+constexpr int IG_KC = 16;   // K chunk
+constexpr int IG_KS = 16;   // LDS row pitch in floats: unpadded; quad g of row r lives in slot g ^ ((r >> 2) & 3)
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // ---------------------------------------------------------------------------------------------
-// policies
+// policies.  Common interface:
+//   rows(), cols(), k_begin(z), k_end(z)
+//   Ctx / init(ctx, tid, m0, z)                      per-thread constants of the tile
+//   KCtx / kprep(tid, kc, z)                         per-thread constants of one chunk
+//   wmap(q, TN, row, k4) / xmap(q, TM, row, k4)      which quad of the W / X tile is quad number q
+//   wquad<TN>(ctx, kctx, q, n0, kc, z) / xquad<TM>(ctx, kctx, q, m0, kc, z)
+//   col(m, z) / store(col, n, v, z)
 // ---------------------------------------------------------------------------------------------
 template <int WM>
 struct OpDown {
+    static constexpr int TM = 128 * WM, MD = TM > 256 ? TM / 256 : 1;
     Geom g;
     const float* __restrict__ L;
     const float* __restrict__ w;
@@ -37,8 +53,11 @@ struct OpDown {
     float* __restrict__ S;
     int nsplit, ksplit;   // K slices (blockIdx.z) of ksplit chunks; nsplit > 1: S is pre-zeroed and added to atomically
     struct Ctx {
-        long long xbase[WM];
-        unsigned vmask[WM];
+        long long xbase[MD];
+        unsigned vmask[MD];
+    };
+    struct KCtx {
+        long long plane;
     };
     __device__ int rows() const { return g.Cs; }
     __device__ long long cols() const { return (long long)g.B * g.Hs * g.Ws; }
@@ -47,8 +66,8 @@ struct OpDown {
     __device__ void init(Ctx& c, int tid, long long m0, int) const {
         const int HW = g.Hs * g.Ws;
 #pragma unroll
-        for (int j = 0; j < WM; j++) {
-            const long long m = m0 + (tid & 127) + 128 * j;
+        for (int j = 0; j < MD; j++) {
+            const long long m = m0 + (TM >= 256 ? tid + 256 * j : (tid & (TM - 1)));
             c.vmask[j] = 0;
             c.xbase[j] = 0;
             if (m < cols()) {
@@ -65,32 +84,28 @@ struct OpDown {
             }
         }
     }
-    template <int NW>
-    __device__ void gather(const Ctx& c, int tid, int n0, int kc, int, float* wr, float* xr) const {
-        const int K = g.Cl * 16;
-#pragma unroll
-        for (int i = 0; i < NW; i++) {
-            const int n = n0 + (tid >> 4) + 16 * i;
-            wr[i] = n < g.Cs ? w[(size_t)n * K + kc + (tid & 15)] : 0.f;
-        }
-        const long long plane = (long long)(kc >> 4) * g.Hl * g.Wl;
-#pragma unroll
-        for (int j = 0; j < WM; j++) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int t = (tid >> 7) + 2 * i;
-                xr[j * 8 + i] = (c.vmask[j] >> t) & 1u ? L[c.xbase[j] + plane + (t >> 2) * g.Wl + (t & 3)] : 0.f;
-            }
-        }
+    __device__ KCtx kprep(int, int kc, int) const { return KCtx{(long long)(kc >> 4) * g.Hl * g.Wl}; }
+    __device__ void wmap(int q, int, int& row, int& k4) const { k4 = (q & 3) * 4, row = q >> 2; }
+    __device__ void xmap(int q, int tm, int& row, int& k4) const { row = q & (tm - 1), k4 = (q / tm) * 4; }
+    template <int TN>
+    __device__ float4 wquad(const Ctx&, const KCtx&, int q, int n0, int kc, int) const {
+        const int n = n0 + (q >> 2);
+        return n < g.Cs ? ld4(w + (size_t)n * g.Cl * 16 + kc + (q & 3) * 4) : make_float4(0, 0, 0, 0);
     }
-    template <int NW, int WS, int XS>
-    __device__ void commit(int tid, float* Wb, float* Xb, const float* wr, const float* xr) const {
-#pragma unroll
-        for (int i = 0; i < NW; i++) Wb[(tid & 15) * WS + (tid >> 4) + 16 * i] = wr[i];
-#pragma unroll
-        for (int j = 0; j < WM; j++)
-#pragma unroll
-            for (int i = 0; i < 8; i++) Xb[((tid >> 7) + 2 * i) * XS + (tid & 127) + 128 * j] = xr[j * 8 + i];
+    template <int TM_>
+    __device__ float4 xquad(const Ctx& c, const KCtx& k, int tid, int i, long long, int, int) const {
+        // quad number tid + 256*i: row = q mod TM, ky = q / TM; for TM = 512 the pixel slot (i & 1) and ky (i >> 1) are
+        // compile-time, which keeps the context arrays in registers (a run-time slot index sends them to scratch)
+        const int ky = TM > 256 ? i / MD : (tid + 256 * i) / TM;
+        const int slot = i % MD;
+        const unsigned mk = (c.vmask[slot] >> (4 * ky)) & 15u;
+        const float* p = L + c.xbase[slot] + k.plane + ky * g.Wl;
+        float4 v;
+        v.x = mk & 1u ? p[0] : 0.f;
+        v.y = mk & 2u ? p[1] : 0.f;
+        v.z = mk & 4u ? p[2] : 0.f;
+        v.w = mk & 8u ? p[3] : 0.f;
+        return v;
     }
     // the column (pixel) part of an output address, once per result column; -1: outside
     __device__ long long col(long long m, int) const {
@@ -123,14 +138,19 @@ __global__ void __launch_bounds__(256) k_pack_up_weights(int Cs, int Cl, const f
 
 template <int WM>
 struct OpUp {
+    static constexpr int TM = 128 * WM, MD = TM > 256 ? TM / 256 : 1;
     Geom g;
     const float* __restrict__ S;
     const float* __restrict__ wp;   // packed weights [4][Cl][Cs*4]
     const float* __restrict__ bias;
     float* __restrict__ L;
     struct Ctx {
-        long long sbase[WM];
-        unsigned vmask[WM];
+        long long sbase[MD];
+        unsigned vmask[MD];
+        int off[4];
+    };
+    struct KCtx {
+        int dummy;
     };
     __device__ int rows() const { return g.Cl; }
     __device__ long long cols() const { return (long long)g.B * g.Hs * g.Ws; }
@@ -140,8 +160,10 @@ struct OpUp {
         const int HW = g.Hs * g.Ws;
         const int py = z >> 1, px = z & 1;
 #pragma unroll
-        for (int j = 0; j < WM; j++) {
-            const long long m = m0 + (tid & 127) + 128 * j;
+        for (int t = 0; t < 4; t++) c.off[t] = (py - (t >> 1)) * g.Ws + (px - (t & 1));
+#pragma unroll
+        for (int j = 0; j < MD; j++) {
+            const long long m = m0 + (TM >= 256 ? tid + 256 * j : (tid & (TM - 1)));
             c.vmask[j] = 0;
             c.sbase[j] = 0;
             if (m < cols()) {
@@ -157,34 +179,27 @@ struct OpUp {
             }
         }
     }
-    template <int NW>
-    __device__ void gather(const Ctx& c, int tid, int n0, int kc, int z, float* wr, float* xr) const {
-        const int K = g.Cs * 4, HW = g.Hs * g.Ws;
-        const int py = z >> 1, px = z & 1;
-#pragma unroll
-        for (int i = 0; i < NW; i++) {
-            const int n = n0 + (tid >> 4) + 16 * i;
-            wr[i] = n < g.Cl ? wp[((size_t)z * g.Cl + n) * K + kc + (tid & 15)] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < WM; j++) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int k = kc + (tid >> 7) + 2 * i;
-                const int cs = k >> 2, t = k & 3;
-                const int off = (py - (t >> 1)) * g.Ws + (px - (t & 1));
-                xr[j * 8 + i] = (c.vmask[j] >> t) & 1u ? S[c.sbase[j] + (long long)cs * HW + off] : 0.f;
-            }
-        }
+    __device__ KCtx kprep(int, int, int) const { return KCtx{0}; }
+    __device__ void wmap(int q, int, int& row, int& k4) const { k4 = (q & 3) * 4, row = q >> 2; }
+    __device__ void xmap(int q, int tm, int& row, int& k4) const { row = q & (tm - 1), k4 = (q / tm) * 4; }
+    template <int TN>
+    __device__ float4 wquad(const Ctx&, const KCtx&, int q, int n0, int kc, int z) const {
+        const int n = n0 + (q >> 2);
+        return n < g.Cl ? ld4(wp + ((size_t)z * g.Cl + n) * g.Cs * 4 + kc + (q & 3) * 4) : make_float4(0, 0, 0, 0);
     }
-    template <int NW, int WS, int XS>
-    __device__ void commit(int tid, float* Wb, float* Xb, const float* wr, const float* xr) const {
-#pragma unroll
-        for (int i = 0; i < NW; i++) Wb[(tid & 15) * WS + (tid >> 4) + 16 * i] = wr[i];
-#pragma unroll
-        for (int j = 0; j < WM; j++)
-#pragma unroll
-            for (int i = 0; i < 8; i++) Xb[((tid >> 7) + 2 * i) * XS + (tid & 127) + 128 * j] = xr[j * 8 + i];
+    template <int TM_>
+    __device__ float4 xquad(const Ctx& c, const KCtx&, int tid, int i, long long, int kc, int) const {
+        // one quad = the 2x2 neighbourhood of one input channel; slot / channel offset compile-time for TM = 512
+        const int cs = (kc >> 2) + (TM > 256 ? i / MD : (tid + 256 * i) / TM);
+        const int slot = i % MD;
+        const unsigned mk = c.vmask[slot];
+        const float* p = S + c.sbase[slot] + (long long)cs * g.Hs * g.Ws;
+        float4 v;
+        v.x = mk & 1u ? p[c.off[0]] : 0.f;
+        v.y = mk & 2u ? p[c.off[1]] : 0.f;
+        v.z = mk & 4u ? p[c.off[2]] : 0.f;
+        v.w = mk & 8u ? p[c.off[3]] : 0.f;
+        return v;
     }
     __device__ long long col(long long m, int z) const {
         if (m >= cols()) return -1;
@@ -210,40 +225,47 @@ struct OpWgrad {
     struct Ctx {
         int dummy;
     };
+    struct KCtx {   // the 4 consecutive pixels (one quad along k) this thread gathers in this chunk
+        bool ok;
+        int b, p, y, x0;
+    };
     __device__ int rows() const { return g.Cs; }
     __device__ long long cols() const { return (long long)g.Cl * 16; }
     __device__ int ktotal() const { return g.B * g.Hs * g.Ws; }
     __device__ int k_begin(int z) const { return z * ksplit * IG_KC; }
     __device__ int k_end(int z) const { return min(ktotal(), (z + 1) * ksplit * IG_KC); }
     __device__ void init(Ctx&, int, long long, int) const {}
-    template <int NW>
-    __device__ void gather(const Ctx&, int tid, int n0, int kc, int, float* wr, float* xr, long long m0) const {
+    __device__ KCtx kprep(int tid, int kc, int) const {
+        KCtx k;
         const int HW = g.Hs * g.Ws;
-        const int k = kc + (tid & 15);
-        const bool kok = k < ktotal();
-        const int b = k / HW, p = k - b * HW;
-        const int y = p / g.Ws, x = p - y * g.Ws;
-#pragma unroll
-        for (int i = 0; i < NW; i++) {
-            const int n = n0 + (tid >> 4) + 16 * i;
-            wr[i] = (kok && n < g.Cs) ? S[((size_t)b * g.Cs + n) * HW + p] : 0.f;
-        }
-        const long long lb = (long long)b * g.Cl * g.Hl * g.Wl + (long long)(2 * y - 1) * g.Wl + (2 * x - 1);
-#pragma unroll
-        for (int i = 0; i < 8 * WM; i++) {
-            const int m = (int)m0 + (tid >> 4) + 16 * i;
-            const int cl = m >> 4, ky = (m >> 2) & 3, kx = m & 3;
-            const int Y = 2 * y - 1 + ky, X = 2 * x - 1 + kx;
-            const bool ok = kok && cl < g.Cl && Y >= 0 && Y < g.Hl && X >= 0 && X < g.Wl;
-            xr[i] = ok ? L[lb + (long long)cl * g.Hl * g.Wl + ky * g.Wl + kx] : 0.f;
-        }
+        const int kk = kc + (tid & 3) * 4;
+        k.ok = kk < ktotal();
+        k.b = kk / HW;
+        k.p = kk - k.b * HW;
+        k.y = k.p / g.Ws;
+        k.x0 = k.p - k.y * g.Ws;
+        return k;
     }
-    template <int NW, int WS, int XS>
-    __device__ void commit(int tid, float* Wb, float* Xb, const float* wr, const float* xr) const {
-#pragma unroll
-        for (int i = 0; i < NW; i++) Wb[(tid & 15) * WS + (tid >> 4) + 16 * i] = wr[i];
-#pragma unroll
-        for (int i = 0; i < 8 * WM; i++) Xb[(tid & 15) * XS + (tid >> 4) + 16 * i] = xr[i];
+    __device__ void wmap(int q, int, int& row, int& k4) const { k4 = (q & 3) * 4, row = q >> 2; }
+    __device__ void xmap(int q, int, int& row, int& k4) const { k4 = (q & 3) * 4, row = q >> 2; }
+    template <int TN>
+    __device__ float4 wquad(const Ctx&, const KCtx& k, int q, int n0, int, int) const {
+        const int n = n0 + (q >> 2);
+        return (k.ok && n < g.Cs) ? ld4(S + ((size_t)k.b * g.Cs + n) * g.Hs * g.Ws + k.p) : make_float4(0, 0, 0, 0);
+    }
+    template <int TM_>
+    __device__ float4 xquad(const Ctx&, const KCtx& k, int tid, int i, long long m0, int, int) const {
+        const int m = (int)m0 + ((tid + 256 * i) >> 2);
+        const int cl = m >> 4, ky = (m >> 2) & 3, kx = m & 3;
+        const int Y = 2 * k.y - 1 + ky, X = 2 * k.x0 - 1 + kx;   // X, X+2, X+4, X+6
+        const bool rok = k.ok && cl < g.Cl && Y >= 0 && Y < g.Hl;
+        const float* p = L + (((long long)k.b * g.Cl + (rok ? cl : 0)) * g.Hl + (rok ? Y : 0)) * g.Wl + X;
+        float4 v;
+        v.x = (rok && X >= 0) ? p[0] : 0.f;
+        v.y = rok ? p[2] : 0.f;
+        v.z = rok ? p[4] : 0.f;
+        v.w = (rok && X + 6 < g.Wl) ? p[6] : 0.f;
+        return v;
     }
     __device__ long long col(long long m, int) const { return m < cols() ? m : -1; }
     __device__ void store(long long cb, int n, float v, int) const {
@@ -251,16 +273,6 @@ struct OpWgrad {
         atomicAdd(&acc[(size_t)n * g.Cl * 16 + cb], (double)v);
     }
 };
-
-template <class Op>
-struct is_wgrad {
-    static constexpr bool value = false;
-};
-template <int WM>
-struct is_wgrad<OpWgrad<WM>> {
-    static constexpr bool value = true;
-};
-
 
 // ---------------------------------------------------------------------------------------------
 // plain GEMM through the same tile engine (the Linear layers): D[n][m] = sum_k A[n][k] * Bm[k][m] with arbitrary
@@ -284,61 +296,51 @@ struct OpGemm {
     struct Ctx {
         int dummy;
     };
+    struct KCtx {
+        int dummy;
+    };
     __device__ int rows() const { return nrows; }
     __device__ long long cols() const { return ncols; }
     __device__ int k_begin(int z) const { return z * ksplit * IG_KC; }
     __device__ int k_end(int z) const { return min(K, (z + 1) * ksplit * IG_KC); }
     __device__ void init(Ctx&, int, long long, int) const {}
-    template <int NW>
-    __device__ void gather(const Ctx&, int tid, int n0, int kc, int, float* wr, float* xr, long long m0) const {
-        constexpr int TN = NW * 16, TM = 128 * WM;
-#pragma unroll
-        for (int i = 0; i < NW; i++) {
-            int nl, kl;
-            if (a_sk == 1) {
-                kl = tid & 15, nl = (tid >> 4) + 16 * i;
-            } else {
-                const int e = tid + 256 * i;
-                nl = e % TN, kl = e / TN;
-            }
-            const int n = n0 + nl, k = kc + kl;
-            wr[i] = (n < nrows && k < K) ? a[n * a_sn + k * a_sk] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 8 * WM; i++) {
-            int ml, kl;
-            if (b_sk == 1) {
-                kl = tid & 15, ml = (tid >> 4) + 16 * i;
-            } else {
-                const int e = tid + 256 * i;
-                ml = e % TM, kl = e / TM;
-            }
-            const long long m = m0 + ml;
-            const int k = kc + kl;
-            xr[i] = (m < ncols && k < K) ? b[k * b_sk + m * b_sm] : 0.f;
-        }
+    __device__ KCtx kprep(int, int, int) const { return KCtx{0}; }
+    __device__ void wmap(int q, int tn, int& row, int& k4) const {
+        if (a_sk == 1) k4 = (q & 3) * 4, row = q >> 2;
+        else row = q & (tn - 1), k4 = (q / tn) * 4;
     }
-    template <int NW, int WS, int XS>
-    __device__ void commit(int tid, float* Wb, float* Xb, const float* wr, const float* xr) const {
-        constexpr int TN = NW * 16, TM = 128 * WM;
-#pragma unroll
-        for (int i = 0; i < NW; i++) {
-            if (a_sk == 1) {
-                Wb[(tid & 15) * WS + (tid >> 4) + 16 * i] = wr[i];
-            } else {
-                const int e = tid + 256 * i;
-                Wb[(e / TN) * WS + e % TN] = wr[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8 * WM; i++) {
-            if (b_sk == 1) {
-                Xb[(tid & 15) * XS + (tid >> 4) + 16 * i] = xr[i];
-            } else {
-                const int e = tid + 256 * i;
-                Xb[(e / TM) * XS + e % TM] = xr[i];
-            }
-        }
+    __device__ void xmap(int q, int tm, int& row, int& k4) const {
+        if (b_sk == 1) k4 = (q & 3) * 4, row = q >> 2;
+        else row = q & (tm - 1), k4 = (q / tm) * 4;
+    }
+    template <int TN>
+    __device__ float4 wquad(const Ctx&, const KCtx&, int q, int n0, int kc, int) const {
+        int row, k4;
+        wmap(q, TN, row, k4);
+        const int n = n0 + row, k = kc + k4;
+        const bool ok = n < nrows;
+        const float* p = a + (ok ? n * a_sn : 0) + k * a_sk;
+        float4 v;
+        v.x = (ok && k < K) ? p[0] : 0.f;
+        v.y = (ok && k + 1 < K) ? p[a_sk] : 0.f;
+        v.z = (ok && k + 2 < K) ? p[2 * a_sk] : 0.f;
+        v.w = (ok && k + 3 < K) ? p[3 * a_sk] : 0.f;
+        return v;
+    }
+    template <int TM_>
+    __device__ float4 xquad(const Ctx&, const KCtx&, int tid, int i, long long m0, int kc, int) const {
+        int row, k4;
+        xmap(tid + 256 * i, TM_, row, k4);
+        const long long m = m0 + row;
+        const int k = kc + k4;
+        const bool ok = m < ncols;
+        const float* p = b + k * b_sk + (ok ? m * b_sm : 0);
+        float4 v;
+        v.x = (ok && k < K) ? p[0] : 0.f;
+        v.y = (ok && k + 1 < K) ? p[b_sk] : 0.f;
+        v.z = (ok && k + 2 < K) ? p[2 * b_sk] : 0.f;
+        v.w = (ok && k + 3 < K) ? p[3 * b_sk] : 0.f;
+        return v;
     }
     __device__ long long col(long long m, int) const { return m < ncols ? m : -1; }
     __device__ void store(long long m, int n, float v, int) const {
@@ -352,19 +354,15 @@ struct OpGemm {
         }
     }
 };
-template <int WM>
-struct is_wgrad<OpGemm<WM>> {
-    static constexpr bool value = true;   // same gather signature (takes m0)
-};
 
-
-// grid (col tiles, row tiles, z): z = output parity (up) or K slice (wgrad)
+// grid (col tiles, row tiles, z): z = output parity (up) or K slice (down, wgrad, gemm)
 template <int WN, int WM, class Op>
 __global__ void __launch_bounds__(256) k_igemm(Op op) {
-    constexpr int TN = 32 * WN, TM = 128 * WM, KC = IG_KC, WS = TN + 1, XS = TM + 1;
-    constexpr int NW = TN / 16, NX = 8 * WM;
-    constexpr int BUF = KC * (WS + XS);
-    extern __shared__ float lds[];
+    constexpr int TN = 32 * WN, TM = 128 * WM, KC = IG_KC, KS = IG_KS;
+    constexpr int NWQ = (TN * 4 + 255) / 256, NXQ = TM * 4 / 256;   // quads per thread and chunk
+    constexpr int BUF = (TN + TM) * KS;
+    extern __shared__ float4 lds4[];
+    float* lds = reinterpret_cast<float*>(lds4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WM, wm = wave - wn * WM;
     const long long m0 = (long long)blockIdx.x * TM;
@@ -377,37 +375,67 @@ __global__ void __launch_bounds__(256) k_igemm(Op op) {
     for (int c = 0; c < 4; c++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[c][r] = 0.f;
-    float wr[NW], xr[NX];
+    float4 wq[NWQ], xq[NXQ];
     const int kb = op.k_begin(z), ke = op.k_end(z);
     auto gather = [&](int kc) {
-        if constexpr (is_wgrad<Op>::value) op.template gather<NW>(ctx, tid, n0, kc, z, wr, xr, m0);
-        else op.template gather<NW>(ctx, tid, n0, kc, z, wr, xr);
+        const typename Op::KCtx kx = op.kprep(tid, kc, z);
+#pragma unroll
+        for (int i = 0; i < NWQ; i++) {
+            const int q = tid + 256 * i;
+            wq[i] = (TN * 4 >= 256 || q < TN * 4) ? op.template wquad<TN>(ctx, kx, q, n0, kc, z) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NXQ; i++) xq[i] = op.template xquad<TM>(ctx, kx, tid, i, m0, kc, z);
+    };
+    auto commit = [&](float* Wb) {
+        float* Xb = Wb + TN * KS;
+#pragma unroll
+        for (int i = 0; i < NWQ; i++) {
+            const int q = tid + 256 * i;
+            if (TN * 4 >= 256 || q < TN * 4) {
+                int row, k4;
+                op.wmap(q, TN, row, k4);
+                *reinterpret_cast<float4*>(Wb + row * KS + (k4 ^ (((row >> 2) & 3) << 2))) = wq[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NXQ; i++) {
+            int row, k4;
+            op.xmap(tid + 256 * i, TM, row, k4);
+            *reinterpret_cast<float4*>(Xb + row * KS + (k4 ^ (((row >> 2) & 3) << 2))) = xq[i];
+        }
     };
     if (kb < ke) {
         gather(kb);
-        op.template commit<NW, WS, XS>(tid, lds, lds + KC * WS, wr, xr);
+        commit(lds);
     }
     __syncthreads();
     int buf = 0;
+    const int swz = ((lane >> 2) & 3) << 2;   // = ((row >> 2) & 3) * 4: tile row bases are multiples of 32
+    const int arow = (wn * 32 + (lane & 31)) * KS, brow = (wm * 128 + (lane & 31)) * KS;
+    const int h4 = 4 * (lane >> 5);
     for (int kc = kb; kc < ke; kc += KC) {
         const bool more = kc + KC < ke;
         if (more) gather(kc + KC);
         const float* Wb = lds + buf * BUF;
-        const float* Xb = Wb + KC * WS;
+        const float* Xb = Wb + TN * KS;
 #pragma unroll
-        for (int kk = 0; kk < KC; kk += 2) {
-            const int kr = kk + (lane >> 5);
-            const float a = Wb[kr * WS + wn * 32 + (lane & 31)];
+        for (int G = 0; G < KC / 8; G++) {
+            const int ko = (8 * G + h4) ^ swz;
+            const float4 a4 = ld4(Wb + arow + ko);
+            float4 b4[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const float b = Xb[kr * XS + wm * 128 + c * 32 + (lane & 31)];
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
-            }
+            for (int c = 0; c < 4; c++) b4[c] = ld4(Xb + brow + c * 32 * KS + ko);
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[c].x, acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[c].y, acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[c].z, acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[c].w, acc[c], 0, 0, 0);
         }
-        if (more) {
-            float* Wn = lds + (buf ^ 1) * BUF;
-            op.template commit<NW, WS, XS>(tid, Wn, Wn + KC * WS, wr, xr);
-        }
+        if (more) commit(lds + (buf ^ 1) * BUF);
         __syncthreads();
         buf ^= 1;
     }
@@ -431,32 +459,36 @@ inline bool mfma_geom(const Geom& g) {
 }
 inline bool mfma_down_eligible(const Geom& g) { return mfma_geom(g) && g.Cs >= 8; }
 inline bool mfma_up_eligible(const Geom& g) { return mfma_geom(g) && g.Cs % 4 == 0 && g.Cs >= 8; }
-inline bool mfma_wgrad_eligible(const Geom& g) { return mfma_geom(g) && g.Cs >= 8; }
+// the 16-byte loads of S along x need rows of S that are multiples of 4 pixels
+inline bool mfma_wgrad_eligible(const Geom& g) { return mfma_geom(g) && g.Cs >= 8 && g.Ws % 4 == 0; }
 
+template <int WN, int WM, class Op>
+inline void igemm_launch(const Op& op, dim3 grid, hipStream_t s) {
+    constexpr size_t bytes = (size_t)2 * (32 * WN + 128 * WM) * IG_KS * sizeof(float);
+    static bool raised = false;   // above the 64 KiB a kernel gets without asking
+    if (bytes > 65536 && !raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<WN, WM, Op>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        raised = true;
+    }
+    hipLaunchKernelGGL((k_igemm<WN, WM, Op>), grid, dim3(256), bytes, s, op);
+}
+
+// tile shape by row count: 32 x 512, 64 x 256 or 128 x 128
 template <template <int> class OpT, class Fill>
 inline void igemm_dispatch(int rows, long long cols, int zdim, hipStream_t s, Fill fill) {
-    auto lds_bytes = [](int WN, int WM) { return (size_t)2 * IG_KC * ((32 * WN + 1) + (128 * WM + 1)) * sizeof(float); };
     if (rows <= 32) {
         OpT<4> op;
         fill(op);
-        static bool big_lds = false;   // 69,888 B: above the 64 KiB a kernel gets without asking
-        if (!big_lds) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<1, 4, OpT<4>>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(1, 4));
-            big_lds = true;
-        }
-        hipLaunchKernelGGL((k_igemm<1, 4, OpT<4>>), dim3((unsigned)((cols + 511) / 512), (rows + 31) / 32, zdim), dim3(256),
-                           lds_bytes(1, 4), s, op);
+        igemm_launch<1, 4>(op, dim3((unsigned)((cols + 511) / 512), (rows + 31) / 32, zdim), s);
     } else if (rows <= 64) {
         OpT<2> op;
         fill(op);
-        hipLaunchKernelGGL((k_igemm<2, 2, OpT<2>>), dim3((unsigned)((cols + 255) / 256), (rows + 63) / 64, zdim), dim3(256),
-                           lds_bytes(2, 2), s, op);
+        igemm_launch<2, 2>(op, dim3((unsigned)((cols + 255) / 256), (rows + 63) / 64, zdim), s);
     } else {
         OpT<1> op;
         fill(op);
-        hipLaunchKernelGGL((k_igemm<4, 1, OpT<1>>), dim3((unsigned)((cols + 127) / 128), (rows + 127) / 128, zdim), dim3(256),
-                           lds_bytes(4, 1), s, op);
+        igemm_launch<4, 1>(op, dim3((unsigned)((cols + 127) / 128), (rows + 127) / 128, zdim), s);
     }
 }
 
