@@ -17,9 +17,9 @@
 //   * registers -> LDS: one ds_write_b128 per quad;
 //   * LDS -> MFMA operands: one ds_read_b128 per row gives a lane its operand for FOUR k-steps (lanes 0-31 take
 //     k = 8G+j, lanes 32-63 k = 8G+4+j, j = 0..3), so a chunk is 10 LDS reads per wave for 32 MFMAs.
-// Rows are unpadded (64 bytes); the four quads of row r are stored XOR-swizzled by (r >> 2) & 3, which makes the
-// 16-byte reads of every ds_read_b128 lane group hit 16 different quads (bank-conflict free) without spending LDS
-// on padding (two 32 x 512 tiles fit one CU).  The gathers of chunk c+1 are in flight while chunk c is multiplied.
+// Rows are unpadded (64 bytes); the four quads of a row are stored XOR-swizzled (ig_swz), which makes the 16-byte
+// reads of every ds_read_b128 lane group and the 16-byte writes of 8 consecutive rows bank-conflict free without
+// spending LDS on padding (two 32 x 512 tiles fit one CU).  The gathers of chunk c+1 are in flight while chunk c is multiplied.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,9 +30,14 @@ namespace unet {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int IG_KC = 16;   // K chunk
-constexpr int IG_KS = 16;   // LDS row pitch in floats: unpadded; quad g of row r lives in slot g ^ ((r >> 2) & 3)
+constexpr int IG_KS = 16;   // LDS row pitch in floats: unpadded, quads XOR-swizzled (ig_swz)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// LDS swizzle: quad g of tile row r is stored in quad slot g ^ s(r), s = {bit 2, bit 1 ^ bit 3} of r.  Found by
+// exhaustive search over XOR-of-bits functions: it is conflict-free both for the ds_read_b128 lane groups
+// ({0-3,12-15,20-27}, ...: 16 rows, one quad each, 64 banks) and for ds_write_b128 by 8 consecutive rows (32 banks).
+__device__ __forceinline__ int ig_swz(int r) { return (((r >> 2) & 1) | ((((r >> 1) ^ (r >> 3)) & 1) << 1)) << 2; }
 
 // ---------------------------------------------------------------------------------------------
 // policies.  Common interface:
@@ -395,14 +400,14 @@ __global__ void __launch_bounds__(256) k_igemm(Op op) {
             if (TN * 4 >= 256 || q < TN * 4) {
                 int row, k4;
                 op.wmap(q, TN, row, k4);
-                *reinterpret_cast<float4*>(Wb + row * KS + (k4 ^ (((row >> 2) & 3) << 2))) = wq[i];
+                *reinterpret_cast<float4*>(Wb + row * KS + (k4 ^ ig_swz(row))) = wq[i];
             }
         }
 #pragma unroll
         for (int i = 0; i < NXQ; i++) {
             int row, k4;
             op.xmap(tid + 256 * i, TM, row, k4);
-            *reinterpret_cast<float4*>(Xb + row * KS + (k4 ^ (((row >> 2) & 3) << 2))) = xq[i];
+            *reinterpret_cast<float4*>(Xb + row * KS + (k4 ^ ig_swz(row))) = xq[i];
         }
     };
     if (kb < ke) {
@@ -411,7 +416,7 @@ __global__ void __launch_bounds__(256) k_igemm(Op op) {
     }
     __syncthreads();
     int buf = 0;
-    const int swz = ((lane >> 2) & 3) << 2;   // = ((row >> 2) & 3) * 4: tile row bases are multiples of 32
+    const int swz = ig_swz(lane & 31);        // tile row bases are multiples of 32
     const int arow = (wn * 32 + (lane & 31)) * KS, brow = (wm * 128 + (lane & 31)) * KS;
     const int h4 = 4 * (lane >> 5);
     for (int kc = kb; kc < ke; kc += KC) {
@@ -527,7 +532,10 @@ inline void mfma_wgrad_launch(const Geom& g, const float* S, const float* L, dou
     const int TN = rows <= 32 ? 32 : rows <= 64 ? 64 : 128, TM = rows <= 32 ? 512 : rows <= 64 ? 256 : 128;
     const long long tiles = ((rows + TN - 1) / TN) * ((cols + TM - 1) / TM);
     const int chunks = (g.B * g.Hs * g.Ws + IG_KC - 1) / IG_KC;
-    long long want = (1024 + tiles - 1) / tiles;          // aim at ~1024 workgroups
+#ifndef IG_WGRAD_BLOCKS
+#define IG_WGRAD_BLOCKS 512
+#endif
+    long long want = (IG_WGRAD_BLOCKS + tiles - 1) / tiles;   // workgroups to aim at: every one ends in rows*cols fp64 atomics
     if (want < 1) want = 1;
     int per = (int)((chunks + want - 1) / want);
     if (per < 8) per = 8;                                 // at least 128 pixels per slice
