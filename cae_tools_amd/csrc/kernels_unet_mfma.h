@@ -97,7 +97,7 @@ struct OpDown {
         const int n = n0 + (q >> 2);
         return n < g.Cs ? ld4(w + (size_t)n * g.Cl * 16 + kc + (q & 3) * 4) : make_float4(0, 0, 0, 0);
     }
-    template <int TM_>
+    template <int TM_, int NT>
     __device__ float4 xquad(const Ctx& c, const KCtx& k, int tid, int i, long long, int, int) const {
         // quad number tid + 256*i: row = q mod TM, ky = q / TM; for TM = 512 the pixel slot (i & 1) and ky (i >> 1) are
         // compile-time, which keeps the context arrays in registers (a run-time slot index sends them to scratch)
@@ -192,7 +192,7 @@ struct OpUp {
         const int n = n0 + (q >> 2);
         return n < g.Cl ? ld4(wp + ((size_t)z * g.Cl + n) * g.Cs * 4 + kc + (q & 3) * 4) : make_float4(0, 0, 0, 0);
     }
-    template <int TM_>
+    template <int TM_, int NT>
     __device__ float4 xquad(const Ctx& c, const KCtx&, int tid, int i, long long, int kc, int) const {
         // one quad = the 2x2 neighbourhood of one input channel; slot / channel offset compile-time for TM = 512
         const int cs = (kc >> 2) + (TM > 256 ? i / MD : (tid + 256 * i) / TM);
@@ -258,9 +258,9 @@ struct OpWgrad {
         const int n = n0 + (q >> 2);
         return (k.ok && n < g.Cs) ? ld4(S + ((size_t)k.b * g.Cs + n) * g.Hs * g.Ws + k.p) : make_float4(0, 0, 0, 0);
     }
-    template <int TM_>
+    template <int TM_, int NT>
     __device__ float4 xquad(const Ctx&, const KCtx& k, int tid, int i, long long m0, int, int) const {
-        const int m = (int)m0 + ((tid + 256 * i) >> 2);
+        const int m = (int)m0 + ((tid + NT * i) >> 2);
         const int cl = m >> 4, ky = (m >> 2) & 3, kx = m & 3;
         const int Y = 2 * k.y - 1 + ky, X = 2 * k.x0 - 1 + kx;   // X, X+2, X+4, X+6
         const bool rok = k.ok && cl < g.Cl && Y >= 0 && Y < g.Hl;
@@ -332,10 +332,10 @@ struct OpGemm {
         v.w = (ok && k + 3 < K) ? p[3 * a_sk] : 0.f;
         return v;
     }
-    template <int TM_>
+    template <int TM_, int NT>
     __device__ float4 xquad(const Ctx&, const KCtx&, int tid, int i, long long m0, int kc, int) const {
         int row, k4;
-        xmap(tid + 256 * i, TM_, row, k4);
+        xmap(tid + NT * i, TM_, row, k4);
         const long long m = m0 + row;
         const int k = kc + k4;
         const bool ok = m < ncols;
@@ -360,11 +360,13 @@ struct OpGemm {
     }
 };
 
-// grid (col tiles, row tiles, z): z = output parity (up) or K slice (down, wgrad, gemm)
+// grid (col tiles, row tiles, z): z = output parity (up) or K slice (down, wgrad, gemm).  WN*WM waves per workgroup:
+// 4 for the convolutions; 1 (a 32 x 128 tile per single-wave workgroup, K sliced finely over blockIdx.z) for the weight
+// gradients of layers with a handful of channels on one side, whose whole output is smaller than one 4-wave tile.
 template <int WN, int WM, class Op>
 __global__ void __launch_bounds__(256) k_igemm(Op op) {
-    constexpr int TN = 32 * WN, TM = 128 * WM, KC = IG_KC, KS = IG_KS;
-    constexpr int NWQ = (TN * 4 + 255) / 256, NXQ = TM * 4 / 256;   // quads per thread and chunk
+    constexpr int TN = 32 * WN, TM = 128 * WM, KC = IG_KC, KS = IG_KS, NT = 64 * WN * WM;
+    constexpr int NWQ = (TN * 4 + NT - 1) / NT, NXQ = TM * 4 / NT;   // quads per thread and chunk
     constexpr int BUF = (TN + TM) * KS;
     extern __shared__ float4 lds4[];
     float* lds = reinterpret_cast<float*>(lds4);
@@ -386,18 +388,18 @@ __global__ void __launch_bounds__(256) k_igemm(Op op) {
         const typename Op::KCtx kx = op.kprep(tid, kc, z);
 #pragma unroll
         for (int i = 0; i < NWQ; i++) {
-            const int q = tid + 256 * i;
-            wq[i] = (TN * 4 >= 256 || q < TN * 4) ? op.template wquad<TN>(ctx, kx, q, n0, kc, z) : make_float4(0, 0, 0, 0);
+            const int q = tid + NT * i;
+            wq[i] = (TN * 4 % NT == 0 || q < TN * 4) ? op.template wquad<TN>(ctx, kx, q, n0, kc, z) : make_float4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NXQ; i++) xq[i] = op.template xquad<TM>(ctx, kx, tid, i, m0, kc, z);
+        for (int i = 0; i < NXQ; i++) xq[i] = op.template xquad<TM, NT>(ctx, kx, tid, i, m0, kc, z);
     };
     auto commit = [&](float* Wb) {
         float* Xb = Wb + TN * KS;
 #pragma unroll
         for (int i = 0; i < NWQ; i++) {
-            const int q = tid + 256 * i;
-            if (TN * 4 >= 256 || q < TN * 4) {
+            const int q = tid + NT * i;
+            if (TN * 4 % NT == 0 || q < TN * 4) {
                 int row, k4;
                 op.wmap(q, TN, row, k4);
                 *reinterpret_cast<float4*>(Wb + row * KS + (k4 ^ ig_swz(row))) = wq[i];
@@ -406,7 +408,7 @@ __global__ void __launch_bounds__(256) k_igemm(Op op) {
 #pragma unroll
         for (int i = 0; i < NXQ; i++) {
             int row, k4;
-            op.xmap(tid + 256 * i, TM, row, k4);
+            op.xmap(tid + NT * i, TM, row, k4);
             *reinterpret_cast<float4*>(Xb + row * KS + (k4 ^ ig_swz(row))) = xq[i];
         }
     };
@@ -476,7 +478,7 @@ inline void igemm_launch(const Op& op, dim3 grid, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         raised = true;
     }
-    hipLaunchKernelGGL((k_igemm<WN, WM, Op>), grid, dim3(256), bytes, s, op);
+    hipLaunchKernelGGL((k_igemm<WN, WM, Op>), grid, dim3(64 * WN * WM), bytes, s, op);
 }
 
 // tile shape by row count: 32 x 512, 64 x 256 or 128 x 128
@@ -529,6 +531,16 @@ inline void mfma_up_launch(const Geom& g, const float* S, const float* w, const 
 inline void mfma_wgrad_launch(const Geom& g, const float* S, const float* L, double* acc, hipStream_t s) {
     const int rows = g.Cs;
     const long long cols = (long long)g.Cl * 16;
+    if (cols <= 128) {   // <= 8 channels on the big side: single-wave 32 x 128 tiles, the parallelism comes from K
+        const int chunks = (g.B * g.Hs * g.Ws + IG_KC - 1) / IG_KC;
+        const int rt = (rows + 31) / 32;
+        int per = (chunks * rt + 2047) / 2048;                // ~2048 single-wave workgroups (8 per CU)
+        if (per < 8) per = 8;
+        OpWgrad<1> op;
+        op.g = g, op.S = S, op.L = L, op.acc = acc, op.ksplit = per;
+        igemm_launch<1, 1>(op, dim3(1, rt, (chunks + per - 1) / per), s);
+        return;
+    }
     const int TN = rows <= 32 ? 32 : rows <= 64 ? 64 : 128, TM = rows <= 32 ? 512 : rows <= 64 ? 256 : 128;
     const long long tiles = ((rows + TN - 1) / TN) * ((cols + TM - 1) / TM);
     const int chunks = (g.B * g.Hs * g.Ws + IG_KC - 1) / IG_KC;
