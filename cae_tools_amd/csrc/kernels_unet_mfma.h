@@ -531,14 +531,17 @@ inline void mfma_up_launch(const Geom& g, const float* S, const float* w, const 
 inline void mfma_wgrad_launch(const Geom& g, const float* S, const float* L, double* acc, hipStream_t s) {
     const int rows = g.Cs;
     const long long cols = (long long)g.Cl * 16;
-    if (cols <= 128) {   // <= 8 channels on the big side: single-wave 32 x 128 tiles, the parallelism comes from K
+#ifndef IG_WG1
+#define IG_WG1 128
+#endif
+    if (cols <= IG_WG1) {   // <= 8 channels on the big side: single-wave 32 x 128 tiles, the parallelism comes from K
         const int chunks = (g.B * g.Hs * g.Ws + IG_KC - 1) / IG_KC;
-        const int rt = (rows + 31) / 32;
-        int per = (chunks * rt + 2047) / 2048;                // ~2048 single-wave workgroups (8 per CU)
+        const int rt = (rows + 31) / 32, ct = (int)((cols + 127) / 128);
+        int per = (int)(((long long)chunks * rt * ct + 2047) / 2048);                // ~2048 single-wave workgroups (8 per CU)
         if (per < 8) per = 8;
         OpWgrad<1> op;
         op.g = g, op.S = S, op.L = L, op.acc = acc, op.ksplit = per;
-        igemm_launch<1, 1>(op, dim3(1, rt, (chunks + per - 1) / per), s);
+        igemm_launch<1, 1>(op, dim3(ct, rt, (chunks + per - 1) / per), s);
         return;
     }
     const int TN = rows <= 32 ? 32 : rows <= 64 ? 64 : 128, TM = rows <= 32 ? 512 : rows <= 64 ? 256 : 128;

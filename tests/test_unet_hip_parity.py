@@ -215,3 +215,36 @@ def test_mfma_path_at_medium_size_against_oracle_and_generic_kernels():
             _close(res[specialised][0][k].numpy(), w.numpy(), 1.5e-2, 1e-6, f"{k} (specialised={specialised})")
     np.testing.assert_allclose(res[True][2], res[False][2], rtol=0, atol=2e-5)
     np.testing.assert_allclose(res[True][2], o.eval_forward(x).numpy(), rtol=0, atol=2e-5)
+
+
+def test_benchmark_geometry_full_size_against_oracle():
+    """BASELINE cfg3 layers (3x256x256, channels 32/64/128/256, fc128/latent32) at batch 5: every MFMA tile shape, the
+    split-K paths, the thin-layer kernels and the 65536-wide Linear layers at their real sizes against the CPU oracle
+    (not batch 2: BatchNorm1d over two samples maps every feature to +-1 and amplifies fp32 rounding without bound)"""
+    from cae_tools_amd.models.unet import Decoder, Encoder, unet_layer_spec
+    from cae_tools_amd.unet_engine import UnetEngine
+    from oracle import unet_oracle as uo
+    torch.set_num_threads(8)
+    spec = unet_layer_spec(3, 3, (256, 256), [32, 64, 128, 256])
+    (fc, latent, B) = (128, 32, 5)
+    torch.manual_seed(11)
+    enc = Encoder(spec.get_input_layers(), latent, fc)
+    dec = Decoder(spec.get_output_layers(), latent, fc)
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand((B, 3, 256, 256), generator=g)
+    t = torch.rand((B, 3, 256, 256), generator=g)
+    m = (torch.rand((B, 1, 256, 256), generator=g) < 0.9).float()
+    o = uo.UnetOracle(spec.save(), enc.state_dict(), dec.state_dict(), dropout_rate=0.1, seed=21)
+    (mse, pl, _) = o.loss_and_grads(x, t, m)
+    want = o.grads()
+    eng = UnetEngine(spec, fc, latent, B, device="cuda:0")
+    eng.load_state(enc.state_dict(), dec.state_dict())
+    eng.set_hyper(dropout_rate=0.1, seed=21)
+    eng.set_dataset(0, x, t, m)
+    got = _grad_dict(eng, eng.forward_backward(0, None, 0, B, slot=0))
+    np.testing.assert_allclose(eng.read_losses(0, 1)[0], [mse, pl], rtol=3e-5)
+    for k, w in want.items():
+        if _feeds_batchnorm(k):
+            continue
+        _close(got[k].numpy(), w.numpy(), 1.5e-2, 1e-6, k)
+    np.testing.assert_allclose(eng.score(x).cpu().numpy(), o.eval_forward(x).numpy(), rtol=0, atol=3e-5)
