@@ -421,17 +421,33 @@ __global__ void __launch_bounds__(256) k_att_fwd(const float* __restrict__ pool,
     }
 }
 
-// cat[b][c][:] = u[b][c][:] * att[b][c];  cat[b][C+c][:] = skip[b][c][:]
+// cat[b][c][:] = u[b][c][:] * att[b][c];  cat[b][C+c][:] = skip[b][c][:];  sums[c2][0..1] += sum cat, sum cat^2 (the
+// BatchNorm statistics of the concatenated tensor, so that no separate pass reads it again).  grid (chunks, 2C)
 __global__ void __launch_bounds__(256) k_scale_concat(const float* __restrict__ u, const float* __restrict__ att,
                                                       const float* __restrict__ skip, int B, int C, int HW,
-                                                      float* __restrict__ cat) {
-    const long long total = (long long)B * 2 * C * HW;
-    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
-        const long long i = o % HW;
-        const long long r = o / HW;
-        const int c2 = (int)(r % (2 * C));
-        const long long b = r / (2 * C);
-        cat[o] = c2 < C ? u[(b * C + c2) * HW + i] * att[b * C + c2] : skip[(b * C + (c2 - C)) * HW + i];
+                                                      float* __restrict__ cat, double* __restrict__ sums) {
+    __shared__ double red[4];
+    const int c2 = blockIdx.y;
+    const bool first = c2 < C;
+    const int c = first ? c2 : c2 - C;
+    const float* src = first ? u : skip;
+    const long long total = (long long)B * HW;
+    double s1 = 0, s2 = 0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long b = e / HW, i = e - b * HW;
+        float v = src[(b * C + c) * HW + i];
+        if (first) v *= att[b * C + c];
+        cat[(b * 2 * C + c2) * HW + i] = v;
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+    }
+    if (sums) {
+        const double t1 = block_sum(s1, red);
+        const double t2 = block_sum(s2, red);
+        if (threadIdx.x == 0) {
+            atomicAdd(&sums[2 * c2], t1);
+            atomicAdd(&sums[2 * c2 + 1], t2);
+        }
     }
 }
 
@@ -498,20 +514,26 @@ __global__ void __launch_bounds__(256) k_att_bwd(const float* __restrict__ pool,
     }
 }
 
-// du[b][c][i] = dcat[b][c][i]*att + davg/HW + [i == argmax]*dmax
+// du[b][c][i] = dcat[b][c][i]*att + davg/HW + [i == argmax]*dmax;  accb[c] += sum du (the ConvTranspose2d bias gradient)
+// grid (chunks, C)
 __global__ void __launch_bounds__(256) k_scale_bwd(const float* __restrict__ dcat, const float* __restrict__ att,
                                                    const float* __restrict__ pool, const float* __restrict__ dpool, int B,
-                                                   int C, int HW, float* __restrict__ du) {
-    const long long total = (long long)B * C * HW;
+                                                   int C, int HW, float* __restrict__ du, double* __restrict__ accb) {
+    __shared__ double red[4];
+    const int c = blockIdx.y;
+    const long long total = (long long)B * HW;
     const float inv = 1.f / (float)HW;
-    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
-        const long long i = o % HW;
-        const long long bc = o / HW;
-        const long long b = bc / C, c = bc - b * C;
+    double s = 0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long b = e / HW, i = e - b * HW;
+        const long long bc = b * C + c;
         float v = dcat[(b * 2 * C + c) * HW + i] * att[bc] + dpool[2 * bc] * inv;
         if ((int)i == __float_as_int(pool[3 * bc + 2])) v += dpool[2 * bc + 1];
-        du[o] = v;
+        du[bc * HW + i] = v;
+        s += (double)v;
     }
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0 && accb) atomicAdd(&accb[c], t);
 }
 
 // ---------------------------------------------------------------------------------------------

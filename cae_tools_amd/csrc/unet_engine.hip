@@ -106,6 +106,7 @@ struct unet_engine {
     uint32_t seed = 0;
     int64_t step = 0;
     int specialised = 1;
+    bool gacc_clean = false;   // the fp64 gradient accumulator is all zero (k_adamw clears what it consumes)
     DataSet ds[2];
 
     float* f(int64_t off) const { return reinterpret_cast<float*>(ws + off_f32) + off; }
@@ -316,9 +317,12 @@ int forward(unet_engine* e, const float* x, int B, bool train) {
         hipLaunchKernelGGL(k_pool, dim3(B * C), dim3(256), 0, e->stream, e->f(L.u), HW, e->f(L.pool));
         hipLaunchKernelGGL(k_att_fwd, dim3(B), dim3(256), (size_t)(2 * C + 2 * L.R) * sizeof(float), e->stream, e->f(L.pool),
                            C, L.R, e->P(L.w1), e->P(L.w2), e->f(L.att), e->f(L.hid));
-        hipLaunchKernelGGL(k_scale_concat, dim3(blocks_for((long long)B * 2 * C * HW, 65536)), dim3(256), 0, e->stream,
-                           e->f(L.u), e->f(L.att), skip, B, C, HW, e->f(L.cat));
-        if (train) bn_stats(e, L.bn, e->f(L.cat), (long long)2 * C * HW, B, HW);
+        // the concat pass also accumulates the BatchNorm sums of what it writes
+        hipLaunchKernelGGL(k_scale_concat, ew_grid(B, 2 * C, HW), dim3(256), 0, e->stream, e->f(L.u), e->f(L.att), skip, B, C,
+                           HW, e->f(L.cat), train ? e->dsum(L.bn.sums) : nullptr);
+        if (train)
+            hipLaunchKernelGGL(k_bn_finalize, dim3((L.bn.C + 255) / 256), dim3(256), 0, e->stream, L.bn.C, e->dsum(L.bn.sums),
+                               (double)B * HW, kEps, kMomentum, e->Bf(L.bn.rmean), e->Bf(L.bn.rvar), e->f(L.bn.saved));
         const Drop d = make_drop(e, SITE_DEC_CONV + j, train);
         bn_act(e, L.bn, e->f(L.cat), (long long)2 * C * HW, B, HW, train, d, nullptr, e->f(L.din_next));
         cur = e->f(L.din_next);
@@ -359,7 +363,8 @@ int loss_forward(unet_engine* e, int which, const int32_t* perm, int64_t start, 
 // ---- backward ---------------------------------------------------------------------------------------
 int backward(unet_engine* e, const float* x, int B) {
     const int n = (int)e->enc.size(), nd = (int)e->dec.size();
-    UHIP_TRY(hipMemsetAsync(e->gacc(0), 0, (size_t)e->n_params * sizeof(double), e->stream));
+    if (!e->gacc_clean) UHIP_TRY(hipMemsetAsync(e->gacc(0), 0, (size_t)e->n_params * sizeof(double), e->stream));
+    e->gacc_clean = false;
     for (int j = nd - 1; j >= 0; j--) {
         ConvLayer& L = e->dec[j];
         Geom g = L.g;
@@ -368,7 +373,8 @@ int backward(unet_engine* e, const float* x, int B) {
         const float* din = j == 0 ? e->f(e->fc[3].a) : e->f(e->dec[j - 1].din_next);
         // ConvTranspose2d: S = input, L = output
         conv_wgrad(e, g, din, e->f(L.gu), e->gacc(L.w));
-        chan_sums(e, e->f(L.gu), (long long)C * HWl, B, C, HWl, e->gacc(L.b), 1, 0);
+        // bias gradient: summed by k_scale_bwd when it produced gu; the last layer's gu comes from the loss kernel
+        if (j == nd - 1) chan_sums(e, e->f(L.gu), (long long)C * HWl, B, C, HWl, e->gacc(L.b), 1, 0);
         conv_down(e, g, e->f(L.gu), e->P(L.w), nullptr, e->f(L.gdin));
         if (j == 0) break;
         // gdin is the gradient wrt dropout(relu(bn(cat_{j-1})))
@@ -381,8 +387,9 @@ int backward(unet_engine* e, const float* x, int B) {
         hipLaunchKernelGGL(k_att_bwd, dim3(B), dim3(256), (size_t)(3 * Cp + 4 * Pv.R) * sizeof(float), e->stream,
                            e->f(Pv.pool), e->f(Pv.att), e->f(Pv.hid), e->f(Pv.da), Cp, Pv.R, e->P(Pv.w1), e->P(Pv.w2),
                            e->gacc(Pv.w1), e->gacc(Pv.w2), e->f(Pv.dpool));
-        hipLaunchKernelGGL(k_scale_bwd, dim3(blocks_for((long long)B * Cp * HWp, 65536)), dim3(256), 0, e->stream,
-                           e->f(Pv.gcat), e->f(Pv.att), e->f(Pv.pool), e->f(Pv.dpool), B, Cp, HWp, e->f(Pv.gu));
+        // ... and accumulates the previous layer's bias gradient while it writes du
+        hipLaunchKernelGGL(k_scale_bwd, ew_grid(B, Cp, HWp), dim3(256), 0, e->stream, e->f(Pv.gcat), e->f(Pv.att),
+                           e->f(Pv.pool), e->f(Pv.dpool), B, Cp, HWp, e->f(Pv.gu), e->gacc(Pv.b));
     }
     // decoder_lin / encoder_lin backward
     const uint32_t sites[4] = {SITE_ENC_FC0, SITE_ENC_FC1, SITE_DEC_FC0, SITE_DEC_FC1};
@@ -466,6 +473,7 @@ int train_or_fb(unet_engine* e, int which, const int32_t* perm, int64_t start, i
         e->step += 1;
         hipLaunchKernelGGL(k_adamw, dim3(blocks_for(e->n_params, 65536)), dim3(256), 0, e->stream, (long long)e->n_params,
                            e->params, e->gacc(0), e->m, e->v, e->hyper, (int)e->step);
+        e->gacc_clean = true;
     }
     UHIP_TRY(hipGetLastError());
     return CAE_OK;
