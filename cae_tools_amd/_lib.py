@@ -94,6 +94,28 @@ SIGNATURES = {
     "unet_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "unet_sync": (C.c_int, [_P]),
     "unet_debug_read": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    # ---- include/cae_vae.h ----
+    "vae_engine_create": (C.c_int, [C.POINTER(LayerSpecC), C.c_int, C.POINTER(LayerSpecC), C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.POINTER(C.c_void_p)]),
+    "vae_engine_destroy": (None, [_P]),
+    "vae_param_count": (C.c_int64, [_P]),
+    "vae_buffer_count": (C.c_int64, [_P]),
+    "vae_tensor_count": (C.c_int, [_P]),
+    "vae_tensor_info": (C.c_int, [_P, C.c_int, _P]),
+    "vae_workspace_bytes": (C.c_int64, [_P]),
+    "vae_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64]),
+    "vae_set_stream": (C.c_int, [_P, _P]),
+    "vae_set_hyper": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                C.c_double, C.c_uint32]),
+    "vae_set_step": (C.c_int, [_P, C.c_int64]),
+    "vae_set_dataset": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
+    "vae_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
+    "vae_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "vae_eval_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
+    "vae_score": (C.c_int, [_P, _P, C.c_int, _P]),
+    "vae_loss_slots": (C.c_int, [_P]),
+    "vae_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "vae_sync": (C.c_int, [_P]),
 }
 
 _lib = None

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 namespace unet {
+namespace {   // internal linkage: this header is compiled into more than one translation unit
 
 // sum of v over the block (any multiple of 64 threads), valid in thread 0.  red: LDS scratch of blockDim/64 doubles.
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -756,4 +757,5 @@ __global__ void __launch_bounds__(256) k_acc_to_f32(long long n, const double* _
         g32[i] = (float)(gacc[i] * scale);
 }
 
+}  // namespace
 }  // namespace unet

@@ -26,6 +26,7 @@
 #include "kernels_unet.h"
 
 namespace unet {
+namespace {   // internal linkage: this header is compiled into more than one translation unit
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -620,4 +621,5 @@ inline void gemm_launch(const GemmDesc& d, double* scratch, hipStream_t s) {
                            d.bias, d.out, d.o_sn, d.o_sm);
 }
 
+}  // namespace
 }  // namespace unet

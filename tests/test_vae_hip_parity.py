@@ -1,0 +1,125 @@
+"""'var' path (include/cae_vae.h) against the build's own CPU definition (oracle/vae_oracle.py).  PARITY UNPINNED with
+respect to the reference: it has no source for this model (see the oracle's header); these tests pin the HIP kernels to
+the published definition only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(in_size, out_size, fc, latent, B, seed, in_ch=1, out_ch=1):
+    from cae_tools_amd.models.decoder import Decoder
+    from cae_tools_amd.models.model_sizer import create_model_spec
+    from cae_tools_amd.models.var_ae_model import VarEncoder
+    spec = create_model_spec(input_size=in_size, input_channels=in_ch, output_size=out_size, output_channels=out_ch)
+    torch.manual_seed(seed)
+    enc = VarEncoder(spec.get_input_layers(), latent, fc)
+    dec = Decoder(spec.get_output_layers(), latent, fc)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.rand((B, in_ch) + tuple(in_size), generator=g)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, out_size[0]), np.linspace(-1, 1, out_size[1]), indexing="ij")
+    t = torch.stack([torch.from_numpy((0.5 + 0.4 * np.sin(3 * yy * (b + 1) + 2 * xx)).astype(np.float32))[None].repeat(out_ch, 1, 1)
+                     for b in range(B)])
+    t = (t + 0.03 * torch.randn(t.shape, generator=g)).clamp(0, 1)
+    return spec, enc, dec, x, t
+
+
+def _engine(spec, enc, dec, fc, latent, B, **hyper):
+    from cae_tools_amd.vae_engine import VaeEngine
+    eng = VaeEngine(spec, fc, latent, B, device="cuda:0")
+    eng.load_state(enc.state_dict(), dec.state_dict())
+    eng.set_hyper(**hyper)
+    return eng
+
+
+def _grad_dict(eng, flat):
+    flat = flat.cpu()
+    return {n: flat[off:off + numel].view(shape) for n, (arena, off, numel, shape) in eng.tensors.items() if arena == 0}
+
+
+def _feeds_batchnorm(key, last_bias):
+    """conv biases (module index 3i) that are followed by a BatchNorm: their exact gradient is 0"""
+    if not key.endswith(".bias") or key == last_bias or not ("encoder_cnn." in key or "decoder_conv." in key):
+        return False
+    return int(key.split(".")[1]) % 3 == 0
+
+
+@pytest.mark.parametrize("lambdas", [(1.0, 1.0, 1.0), (0.5, 0.1, 2.0), (1.0, 0.0, 0.0)])
+def test_losses_and_gradients_match_the_definition(lambdas):
+    from oracle import vae_oracle as vo
+    (fc, latent, B) = (16, 6, 3)
+    (spec, enc, dec, x, t) = _setup((12, 12), (176, 192), fc, latent, B, seed=5)
+    hyper = dict(lambda_mse=lambdas[0], lambda_kl=lambdas[1], lambda_ssim=lambdas[2], seed=9)
+    o = vo.VaeOracle(spec.save(), enc.state_dict(), dec.state_dict(), **hyper)
+    o.step_count = 4
+    eng = _engine(spec, enc, dec, fc, latent, B, **hyper)
+    eng.set_step(4)
+    eng.set_dataset(0, x, t)
+    # eval: z = mu, running statistics
+    np.testing.assert_allclose(eng.score(x).cpu().numpy(), o.eval_forward(x).numpy(), rtol=0, atol=1e-5)
+    eng.eval_step(0, None, 0, B, slot=2)
+    want = o.eval_losses(x, t)
+    got = eng.read_losses(2, 1)[0]
+    np.testing.assert_allclose(got[:3], want, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(got[3], lambdas[0] * want[0] + lambdas[1] * want[1] + lambdas[2] * want[2], rtol=2e-5)
+    # train: reparameterised sample with the shared noise hash
+    g = _grad_dict(eng, eng.forward_backward(0, None, 0, B, slot=0))
+    (parts, _) = o.loss_and_grads(x, t)
+    np.testing.assert_allclose(eng.read_losses(0, 1)[0][:3], parts, rtol=3e-5, atol=1e-7)
+    last_bias = "dec/decoder_conv.%d.bias" % (3 * (len(spec.get_output_layers()) - 1))
+    for k, w in o.grads().items():
+        (gv, wv) = (g[k].numpy().astype(np.float64), w.numpy().astype(np.float64))
+        if _feeds_batchnorm(k, last_bias):
+            assert np.abs(gv).max() < 2e-5 and np.abs(wv).max() < 2e-5, k       # bias in front of a BatchNorm: exactly 0
+            continue
+        assert np.linalg.norm(gv - wv) <= 5e-3 * max(np.linalg.norm(wv), 1e-9), k
+        assert np.abs(gv - wv).max() <= 2e-2 * max(np.abs(wv).max(), 1e-7), k
+
+
+def test_adam_steps_follow_the_definition():
+    from oracle import vae_oracle as vo
+    (fc, latent, B) = (12, 4, 4)
+    (spec, enc, dec, x, t) = _setup((12, 12), (176, 176), fc, latent, B, seed=8)
+    o = vo.VaeOracle(spec.save(), enc.state_dict(), dec.state_dict(), lr=1e-3, weight_decay=1e-5, seed=2)
+    eng = _engine(spec, enc, dec, fc, latent, B, lr=1e-3, weight_decay=1e-5, seed=2)
+    eng.set_dataset(0, x, t)
+    want = [o.train_step(x, t) for _ in range(3)]
+    for i in range(3):
+        eng.train_step(0, None, 0, B, slot=i)
+    got = eng.read_losses(0, 3)
+    np.testing.assert_allclose(np.array(got)[:, :3], np.array(want), rtol=5e-3, atol=1e-6)
+    (e_sd, d_sd) = eng.export_state()
+    ref = o.state()
+    for (pre, sd) in (("enc/", e_sd), ("dec/", d_sd)):
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == 3
+            else:
+                assert np.abs(v.numpy() - ref[pre + k].numpy()).max() <= 3 * 2.1e-3, k   # 3 Adam steps of lr 1e-3
+
+
+def test_benchmark_geometry_cfg5():
+    """BASELINE cfg5: 64x64 -> 512x512, 1 channel: loss parts and the MS-SSIM gradient at full size (batch 2)"""
+    from oracle import vae_oracle as vo
+    torch.set_num_threads(8)
+    (fc, latent, B) = (128, 32, 2)
+    (spec, enc, dec, x, t) = _setup((64, 64), (512, 512), fc, latent, B, seed=13)
+    o = vo.VaeOracle(spec.save(), enc.state_dict(), dec.state_dict(), seed=3)
+    eng = _engine(spec, enc, dec, fc, latent, B, seed=3)
+    eng.set_dataset(0, x, t)
+    g = _grad_dict(eng, eng.forward_backward(0, None, 0, B, slot=0))
+    (parts, _) = o.loss_and_grads(x, t)
+    np.testing.assert_allclose(eng.read_losses(0, 1)[0][:3], parts, rtol=5e-5, atol=1e-7)
+    k = "dec/decoder_conv.%d.weight" % (3 * (len(spec.get_output_layers()) - 1))
+    (gv, wv) = (g[k].numpy().astype(np.float64), o.grads()[k].numpy().astype(np.float64))
+    assert np.linalg.norm(gv - wv) <= 1e-2 * np.linalg.norm(wv)
+
+
+def test_geometry_errors():
+    from cae_tools_amd._lib import CaeError
+    from cae_tools_amd.models.model_sizer import create_model_spec
+    from cae_tools_amd.vae_engine import VaeEngine
+    spec = create_model_spec(input_size=(16, 16), input_channels=1, output_size=(100, 100), output_channels=1)
+    with pytest.raises(CaeError, match="MS-SSIM"):
+        VaeEngine(spec, 8, 4, 2, device="cuda:0")
