@@ -10,6 +10,7 @@ import numpy as np
 from ..data.arrays import DataArray, open_mfdataset
 from ..models.conv_ae_model import ConvAEModel
 from ..models.unet import UNET
+from ..models.var_ae_model import VarAEModel
 
 
 def build_parser():
@@ -28,9 +29,10 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     with open(os.path.join(args.model_folder, "parameters.json")) as f:
         parameters = json.loads(f.read())
-    if parameters["type"] not in ("ConvAEModel", "UNET"):
-        raise SystemExit(f"cae_tools_amd implements ConvAEModel and UNET; model folder holds a {parameters['type']}")
-    mt = ConvAEModel() if parameters["type"] == "ConvAEModel" else UNET()
+    kinds = {"ConvAEModel": ConvAEModel, "UNET": UNET, "VarAEModel": VarAEModel}
+    if parameters["type"] not in kinds:
+        raise SystemExit(f"cae_tools_amd implements {sorted(kinds)}; model folder holds a {parameters['type']}")
+    mt = kinds[parameters["type"]]()
     mt.load(args.model_folder)
 
     model_names = mt.get_input_variable_names()

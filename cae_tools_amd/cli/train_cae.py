@@ -14,6 +14,7 @@ import numpy as np
 from ..data.arrays import DataArray, open_mfdataset
 from ..models.conv_ae_model import ConvAEModel
 from ..models.unet import UNET
+from ..models.var_ae_model import VarAEModel
 from ..models.model_sizer import ModelSpec
 
 
@@ -84,9 +85,10 @@ def main(argv=None):
     if args.continue_training:
         with open(os.path.join(args.model_folder, "parameters.json")) as f:
             parameters = json.loads(f.read())
-        if parameters["type"] not in ("ConvAEModel", "UNET"):
-            raise SystemExit(f"cae_tools_amd implements ConvAEModel and UNET; model folder holds a {parameters['type']}")
-        mt = ConvAEModel() if parameters["type"] == "ConvAEModel" else UNET()
+        kinds = {"ConvAEModel": ConvAEModel, "UNET": UNET, "VarAEModel": VarAEModel}
+        if parameters["type"] not in kinds:
+            raise SystemExit(f"cae_tools_amd implements {sorted(kinds)}; model folder holds a {parameters['type']}")
+        mt = kinds[parameters["type"]]()
         mt.load(args.model_folder)
         mt.nr_epochs = args.nr_epochs
         mt.lr = args.learning_rate
@@ -100,9 +102,14 @@ def main(argv=None):
                       batch_size=args.batch_size, lr=args.learning_rate, lambda_l1=args.lambda_l1,
                       lambda_pearson=args.lambda_pearson, database_path=args.database_path,
                       weight_decay=args.weight_decay, dropout_rate=args.dropout_rate)
+        elif args.method == "var":      # the reference's default method; its model source is missing there
+            mt = VarAEModel(fc_size=args.fc_size, encoded_dim_size=args.latent_size, nr_epochs=args.nr_epochs,
+                            batch_size=args.batch_size, lr=args.learning_rate, lambda_mse=args.lambda_mse,
+                            lambda_kl=args.lambda_kl, lambda_ssim=args.lambda_ssim, weight_decay=args.weight_decay,
+                            database_path=args.database_path)
         else:
-            raise SystemExit(f"--method {args.method}: cae_tools_amd implements the 'conv' (ConvAEModel) and 'unet' "
-                             "(UNET) paths only")
+            raise SystemExit(f"--method {args.method}: cae_tools_amd implements the 'conv' (ConvAEModel), 'unet' (UNET) "
+                             "and 'var' (VarAEModel) paths only")
         if args.model_id:
             mt.set_model_id(args.model_id)
         if args.layer_definitions_path:
