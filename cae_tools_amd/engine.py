@@ -105,6 +105,7 @@ class HipEngine(EnginePlan):
         self._keep = []
         self.loss_slots = int(self.lib.cae_loss_slots(self.handle))
         self._slot = 0
+        self._cursor = None     # host shadow of the device cursor (batch_start, loss_slot); None = unknown
 
     # ---- parameters ------------------------------------------------------------------------
     def _arena(self, arena):
@@ -230,6 +231,17 @@ class HipEngine(EnginePlan):
         self._slot += n
         return first
 
+    def _set_cursor(self, start, slot):
+        """point the device cursor at (start, slot) unless the previous step already left it there (every step
+        advances it by its batch size and one slot): one tiny launch less per step for sequential passes"""
+        if self._cursor != (int(start), int(slot)):
+            check(self.lib.cae_set_cursor(self.handle, int(start), int(slot)))
+        self._cursor = (int(start), int(slot))
+
+    def _advance(self, samples, steps):
+        if self._cursor is not None:
+            self._cursor = (self._cursor[0] + int(samples), self._cursor[1] + int(steps))
+
     def _read_losses(self, first, n):
         out = (C.c_double * n)()
         check(self.lib.cae_read_losses(self.handle, first, n, out))
@@ -242,8 +254,9 @@ class HipEngine(EnginePlan):
         nb = (n + batch_size - 1) // batch_size
         first = self._claim_slots(nb)
         ptr = perm_dev.data_ptr() if perm_dev is not None else None
-        check(self.lib.cae_set_cursor(self.handle, 0, first))
+        self._set_cursor(0, first)
         self._enqueue(which, ptr, n, batch_size, train)
+        self._advance(n, nb)
         if train:
             self.num_batches_tracked += nb
             self.adam_steps += nb
@@ -268,9 +281,10 @@ class HipEngine(EnginePlan):
     def train_step(self, which, perm_dev, start, size):
         """a single training step on perm[start:start+size]; returns its loss (blocking)"""
         first = self._claim_slots(1)
-        check(self.lib.cae_set_cursor(self.handle, int(start), first))
+        self._set_cursor(start, first)
         check(self.lib.cae_train_step(self.handle, which, perm_dev.data_ptr() if perm_dev is not None else None,
                                       int(size)))
+        self._advance(size, 1)
         self.num_batches_tracked += 1
         self.adam_steps += 1
         return self._read_losses(first, 1)[0]
@@ -279,8 +293,9 @@ class HipEngine(EnginePlan):
         """bench helper: enqueue one pass without reading anything back"""
         nb = (n + batch_size - 1) // batch_size
         ptr = perm_dev.data_ptr() if perm_dev is not None else None
-        check(self.lib.cae_set_cursor(self.handle, 0, slot_first))
+        self._set_cursor(0, slot_first)
         self._enqueue(which, ptr, n, batch_size, True)
+        self._advance(n, nb)
         self.num_batches_tracked += nb
         self.adam_steps += nb
         return nb
@@ -288,10 +303,11 @@ class HipEngine(EnginePlan):
     def forward_backward(self, which, perm_dev, start, size, global_batch):
         """DP half-step: gradients of sum/global_count into self.grads (caller all-reduces)"""
         first = self._claim_slots(1)
-        check(self.lib.cae_set_cursor(self.handle, int(start), first))
+        self._set_cursor(start, first)
         check(self.lib.cae_forward_backward(self.handle, which,
                                             perm_dev.data_ptr() if perm_dev is not None else None, int(size),
                                             int(global_batch)))
+        self._advance(size, 1)
         self.num_batches_tracked += 1
         return first
 
@@ -300,7 +316,8 @@ class HipEngine(EnginePlan):
         CUDA view of each BatchNorm sum table and must sum it over the ranks in place, enqueued on
         self.stream (it is called inside `with torch.cuda.stream(self.stream)`)."""
         first = self._claim_slots(1)
-        check(self.lib.cae_set_cursor(self.handle, int(start), first))
+        self._set_cursor(start, first)
+        self._advance(size, 1)
         base = (self.workspace.data_ptr() + 255) // 256 * 256
         pad = base - self.workspace.data_ptr()
         failure = []
