@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -299,13 +300,18 @@ bool s2_shape_ok(const ConvLayer& L) {
 #undef CHK
     return false;
 }
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
 bool s2_eligible(const cae_engine* e, const ConvLayer& L) { return e->use_s2 && L.sh_w >= 0 && s2_shape_ok(L); }
 
 template <int CIN, int COUT, int KH, int KW>
 void s2_fwd_launch(S2Fwd a, hipStream_t s) {
     // grid caps measured on MI355X at batch 64 (workgroups walk the remaining tiles): more workgroups
     // only add fp64-atomic traffic at the end of the kernel
-    const int capf = 1024, capf2 = 512;
+    static const int capf = env_int("CAE_CAP_F", 1024), capf2 = env_int("CAE_CAP_F2", 512);   // env: tuning only
     // each thread covers 2x2 quads; lanes run along the row
     const int px = ((a.OW + 1) / 2 + 1) / 2, py = ((a.OH + 1) / 2 + 1) / 2;   // thread columns / rows per image
     if ((long long)a.B * px * py < 100000) {
@@ -355,7 +361,7 @@ template <int CIN, int COUT, int KH, int KW>
 void s2_bwd_launch(S2Bwd a, hipStream_t s) {
     // 512 workgroups: each ends with Cin*Cout*kh*kw + 2*Cin fp64 atomics, and those dominate beyond that
     // (measured per step at batch 64: 1536 -> 286 us, 512 -> 274 us)
-    const int cap2 = 512, caps = 512;
+    static const int cap2 = env_int("CAE_CAP_B2", 512), caps = env_int("CAE_CAP_BS", 512);
     if constexpr (CIN * COUT * KH * KW <= 72) {
         // direct variant: one input pixel per thread, no LDS staging
         if (a.W > 32) {
