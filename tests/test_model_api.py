@@ -196,3 +196,30 @@ def test_evaluate_on_device_matches_host_metric_and_database(tmp_path):
     assert (emid, etr, ete) == (mid, "tr.nc", "te.nc")
     assert json.loads(em)["test"]["mse"] == pytest.approx(metrics["test"]["mse"])
     conn.close()
+
+
+def test_cli_continue_training(tmp_path):
+    """--continue-training loads the model folder, takes nr_epochs / lr / batch size from the command line
+    (cli/train_cae.py:111-125) and trains on: history and epoch count grow, the model id is kept"""
+    from cae_tools_amd.data import datagen
+    from cae_tools_amd.cli import train_cae
+    tr, te = str(tmp_path / "train.nc"), str(tmp_path / "test.nc")
+    datagen.generate("circle", 10, seed=5).to_netcdf(tr)
+    datagen.generate("circle", 4, seed=6).to_netcdf(te)
+    folder = str(tmp_path / "m")
+    common = ["--train-inputs", tr, "--test-inputs", te, "--model-folder", folder, "--input-variables", "lowres",
+              "--output-variable", "hires", "--method", "conv", "--batch-size", "5"]
+    with redirect_stdout(io.StringIO()):
+        train_cae.main(common + ["--nr-epochs", "11", "--model-id", "fixed-id"])
+    with open(os.path.join(folder, "history.json")) as f:
+        h1 = json.load(f)
+    assert h1["nr_epochs"] == 11 and len(h1["train_loss"]) == 2          # epochs 0 and 10
+    with redirect_stdout(io.StringIO()):
+        train_cae.main(common + ["--nr-epochs", "3", "--continue-training"])
+    with open(os.path.join(folder, "history.json")) as f:
+        h2 = json.load(f)
+    with open(os.path.join(folder, "parameters.json")) as f:
+        p = json.load(f)
+    assert h2["nr_epochs"] == 14 and len(h2["train_loss"]) == 3 and h2["train_loss"][:2] == h1["train_loss"]
+    assert p["model_id"] == "fixed-id" and p["batch_size"] == 5
+    assert h2["train_loss"][2] < h1["train_loss"][0]                   # it kept learning from the loaded weights
