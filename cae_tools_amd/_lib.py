@@ -116,6 +116,23 @@ SIGNATURES = {
     "vae_loss_slots": (C.c_int, [_P]),
     "vae_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "vae_sync": (C.c_int, [_P]),
+    # ---- include/cae_linear.h ----
+    "lin_engine_create": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
+    "lin_engine_destroy": (None, [_P]),
+    "lin_param_count": (C.c_int64, [_P]),
+    "lin_workspace_bytes": (C.c_int64, [_P]),
+    "lin_bind": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64]),
+    "lin_set_stream": (C.c_int, [_P, _P]),
+    "lin_set_hyper": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "lin_set_step": (C.c_int, [_P, C.c_int64]),
+    "lin_set_dataset": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
+    "lin_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
+    "lin_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "lin_eval_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
+    "lin_score": (C.c_int, [_P, _P, C.c_int, _P]),
+    "lin_loss_slots": (C.c_int, [_P]),
+    "lin_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "lin_sync": (C.c_int, [_P]),
 }
 
 _lib = None

@@ -23,6 +23,7 @@ SOURCES = {
     "engine.hip": ["kernels_generic.h", "kernels_s2.h", "kernels_gemm.h", "kernels_igemm.h", "cae_hip.h"],
     "unet_engine.hip": ["kernels_unet.h", "kernels_unet_mfma.h", "cae_unet.h", "cae_hip.h"],
     "vae_engine.hip": ["kernels_unet.h", "kernels_unet_mfma.h", "kernels_vae.h", "cae_vae.h", "cae_hip.h"],
+    "linear_engine.hip": ["kernels_unet.h", "kernels_unet_mfma.h", "kernels_vae.h", "cae_linear.h", "cae_hip.h"],
 }
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-cuda-compat", "-Wno-pass-failed"]
 FLAGS += os.environ.get("CAE_HIPCC_FLAGS", "").split()     # tuning experiments: e.g. CAE_HIPCC_FLAGS=-DIG_KCW=32

@@ -10,6 +10,7 @@ import numpy as np
 from ..data.arrays import DataArray, open_mfdataset
 from ..models.conv_ae_model import ConvAEModel
 from ..models.unet import UNET
+from ..models.linear_model import LinearModel
 from ..models.var_ae_model import VarAEModel
 
 
@@ -29,7 +30,7 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     with open(os.path.join(args.model_folder, "parameters.json")) as f:
         parameters = json.loads(f.read())
-    kinds = {"ConvAEModel": ConvAEModel, "UNET": UNET, "VarAEModel": VarAEModel}
+    kinds = {"ConvAEModel": ConvAEModel, "UNET": UNET, "VarAEModel": VarAEModel, "LinearModel": LinearModel}
     if parameters["type"] not in kinds:
         raise SystemExit(f"cae_tools_amd implements {sorted(kinds)}; model folder holds a {parameters['type']}")
     mt = kinds[parameters["type"]]()

@@ -14,6 +14,7 @@ import numpy as np
 from ..data.arrays import DataArray, open_mfdataset
 from ..models.conv_ae_model import ConvAEModel
 from ..models.unet import UNET
+from ..models.linear_model import LinearModel
 from ..models.var_ae_model import VarAEModel
 from ..models.model_sizer import ModelSpec
 
@@ -85,7 +86,7 @@ def main(argv=None):
     if args.continue_training:
         with open(os.path.join(args.model_folder, "parameters.json")) as f:
             parameters = json.loads(f.read())
-        kinds = {"ConvAEModel": ConvAEModel, "UNET": UNET, "VarAEModel": VarAEModel}
+        kinds = {"ConvAEModel": ConvAEModel, "UNET": UNET, "VarAEModel": VarAEModel, "LinearModel": LinearModel}
         if parameters["type"] not in kinds:
             raise SystemExit(f"cae_tools_amd implements {sorted(kinds)}; model folder holds a {parameters['type']}")
         mt = kinds[parameters["type"]]()
@@ -107,9 +108,11 @@ def main(argv=None):
                             batch_size=args.batch_size, lr=args.learning_rate, lambda_mse=args.lambda_mse,
                             lambda_kl=args.lambda_kl, lambda_ssim=args.lambda_ssim, weight_decay=args.weight_decay,
                             database_path=args.database_path)
+        elif args.method == "linear":   # cli/train_cae.py:137-138
+            mt = LinearModel(batch_size=args.batch_size, nr_epochs=args.nr_epochs, lr=args.learning_rate)
         else:
-            raise SystemExit(f"--method {args.method}: cae_tools_amd implements the 'conv' (ConvAEModel), 'unet' (UNET) "
-                             "and 'var' (VarAEModel) paths only")
+            raise SystemExit(f"--method {args.method}: cae_tools_amd implements 'conv' (ConvAEModel), 'unet' (UNET), 'var' "
+                             "(VarAEModel) and 'linear' (LinearModel)")
         if args.model_id:
             mt.set_model_id(args.model_id)
         if args.layer_definitions_path:

@@ -128,7 +128,7 @@ def test_cli_train_then_apply(tmp_path):
     assert 280 < float(ds["model_output"].values.mean()) < 305
     with pytest.raises(SystemExit):
         train_cae.main(["--train-inputs", tr, "--test-inputs", te, "--model-folder", folder, "--input-variables", "lowres",
-                        "--output-variable", "hires", "--method", "linear"])   # a model family outside the three built paths
+                        "--output-variable", "hires", "--method", "vae"])   # a method name outside the built paths
 
 
 def test_dataset_errors_match_reference_messages():
