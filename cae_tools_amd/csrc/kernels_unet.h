@@ -238,31 +238,39 @@ __global__ void __launch_bounds__(256) k_chan_sums(const float* __restrict__ x, 
     }
 }
 
-// batch statistics -> saved {mean, invstd}; running stats updated as torch does (unbiased running_var)
-__global__ void k_bn_finalize(int C, const double* __restrict__ sums, double N, float eps, float momentum,
-                              float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ saved) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mean = sums[2 * c] / N;
-    double var = sums[2 * c + 1] / N - mean * mean;
-    if (var < 0) var = 0;
-    saved[2 * c] = (float)mean;
-    saved[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    const double unbiased = N > 1 ? var * N / (N - 1) : var;
-    rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + (double)momentum * mean);
-    rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + (double)momentum * unbiased);
-}
-
-// a = dropout(relu(bn(z))), s = relu(bn(z)) (optional).  use_running: mean/var from the running stats.
+// a = dropout(relu(bn(z))), s = relu(bn(z)) (optional).  stat_mode 0: mean / invstd from `saved`; 1: running statistics
+// (eval); 2: batch statistics straight from the fp64 sums {sum, sum of squares} over N values per channel - every
+// workgroup derives its channel's constants itself and the first one of each channel also writes `saved` and updates the
+// running statistics as torch does (unbiased running_var), so that no separate finalize launch is needed.
 // z is read with batch stride zbs; s and a are contiguous (B,C,HW).  grid (chunks, C)
 __global__ void __launch_bounds__(256) k_bn_act(const float* __restrict__ z, long long zbs, int B, int C, int HW,
-                                                const float* __restrict__ saved, const float* __restrict__ rmean,
-                                                const float* __restrict__ rvar, float eps, int use_running,
-                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                Drop d, float* __restrict__ s_out, float* __restrict__ a_out) {
+                                                float* __restrict__ saved, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                float eps, int stat_mode, const double* __restrict__ sums, double N,
+                                                float momentum, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, Drop d, float* __restrict__ s_out,
+                                                float* __restrict__ a_out) {
     const int c = blockIdx.y;
-    const float mean = use_running ? rmean[c] : saved[2 * c];
-    const float invstd = use_running ? 1.f / sqrtf(rvar[c] + eps) : saved[2 * c + 1];
+    float mean, invstd;
+    if (stat_mode == 2) {
+        const double m = sums[2 * c] / N;
+        double var = sums[2 * c + 1] / N - m * m;
+        if (var < 0) var = 0;
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            saved[2 * c] = mean;
+            saved[2 * c + 1] = invstd;
+            const double unbiased = N > 1 ? var * N / (N - 1) : var;
+            rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + (double)momentum * m);
+            rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + (double)momentum * unbiased);
+        }
+    } else if (stat_mode == 1) {
+        mean = rmean[c];
+        invstd = 1.f / sqrtf(rvar[c] + eps);
+    } else {
+        mean = saved[2 * c];
+        invstd = saved[2 * c + 1];
+    }
     const float sc = invstd * gamma[c], sh = beta[c];
     const long long total = (long long)B * HW;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {

@@ -220,17 +220,16 @@ dim3 ew_grid(int B, int C, int HW) {
     return dim3(chunks, C);
 }
 
-// batch statistics of x (B,C,HW; batch stride bs) -> bn.saved, running stats
+// accumulate the batch sums of x (B,C,HW; batch stride bs); bn_act turns them into statistics
 void bn_stats(unet_engine* e, const Bn& bn, const float* x, long long bs, int B, int HW) {
     chan_sums(e, x, bs, B, bn.C, HW, e->dsum(bn.sums), 2, 1);
-    hipLaunchKernelGGL(k_bn_finalize, dim3((bn.C + 255) / 256), dim3(256), 0, e->stream, bn.C, e->dsum(bn.sums),
-                       (double)B * HW, kEps, kMomentum, e->Bf(bn.rmean), e->Bf(bn.rvar), e->f(bn.saved));
 }
 
 void bn_act(unet_engine* e, const Bn& bn, const float* z, long long zbs, int B, int HW, bool train, Drop d, float* s_out,
             float* a_out) {
     hipLaunchKernelGGL(k_bn_act, ew_grid(B, bn.C, HW), dim3(256), 0, e->stream, z, zbs, B, bn.C, HW, e->f(bn.saved),
-                       e->Bf(bn.rmean), e->Bf(bn.rvar), kEps, train ? 0 : 1, e->P(bn.gamma), e->P(bn.beta), d, s_out, a_out);
+                       e->Bf(bn.rmean), e->Bf(bn.rvar), kEps, train ? 2 : 1, e->dsum(bn.sums), (double)B * HW, kMomentum,
+                       e->P(bn.gamma), e->P(bn.beta), d, s_out, a_out);
 }
 
 // BatchNorm+ReLU(+dropout) backward: g_io holds dz on return
@@ -320,9 +319,6 @@ int forward(unet_engine* e, const float* x, int B, bool train) {
         // the concat pass also accumulates the BatchNorm sums of what it writes
         hipLaunchKernelGGL(k_scale_concat, ew_grid(B, 2 * C, HW), dim3(256), 0, e->stream, e->f(L.u), e->f(L.att), skip, B, C,
                            HW, e->f(L.cat), train ? e->dsum(L.bn.sums) : nullptr);
-        if (train)
-            hipLaunchKernelGGL(k_bn_finalize, dim3((L.bn.C + 255) / 256), dim3(256), 0, e->stream, L.bn.C, e->dsum(L.bn.sums),
-                               (double)B * HW, kEps, kMomentum, e->Bf(L.bn.rmean), e->Bf(L.bn.rvar), e->f(L.bn.saved));
         const Drop d = make_drop(e, SITE_DEC_CONV + j, train);
         bn_act(e, L.bn, e->f(L.cat), (long long)2 * C * HW, B, HW, train, d, nullptr, e->f(L.din_next));
         cur = e->f(L.din_next);

@@ -157,14 +157,10 @@ void chan_sums(vae_engine* e, const float* x, long long bs, int B, int C, int HW
 
 // conv output z (B,C,HW) -> a = relu(bn(z)); batch statistics when training
 void bn_relu(vae_engine* e, VBn& bn, const float* z, int B, int HW, bool train, float* a) {
-    if (train) {
-        chan_sums(e, z, (long long)bn.C * HW, B, bn.C, HW, e->dsum(bn.sums), 2, 1);
-        hipLaunchKernelGGL(k_bn_finalize, dim3((bn.C + 255) / 256), dim3(256), 0, e->stream, bn.C, e->dsum(bn.sums),
-                           (double)B * HW, kEps, kMomentum, e->Bf(bn.rmean), e->Bf(bn.rvar), e->f(bn.saved));
-    }
+    if (train) chan_sums(e, z, (long long)bn.C * HW, B, bn.C, HW, e->dsum(bn.sums), 2, 1);
     hipLaunchKernelGGL(k_bn_act, ew_grid(B, bn.C, HW), dim3(256), 0, e->stream, z, (long long)bn.C * HW, B, bn.C, HW, e->f(bn.saved),
-                       e->Bf(bn.rmean), e->Bf(bn.rvar), kEps, train ? 0 : 1, e->P(bn.gamma), e->P(bn.beta), kNoDrop,
-                       (float*)nullptr, a);
+                       e->Bf(bn.rmean), e->Bf(bn.rvar), kEps, train ? 2 : 1, e->dsum(bn.sums), (double)B * HW, kMomentum,
+                       e->P(bn.gamma), e->P(bn.beta), kNoDrop, (float*)nullptr, a);
 }
 
 // g_io: in = grad wrt a, out = grad wrt z
