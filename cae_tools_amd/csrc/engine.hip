@@ -881,6 +881,9 @@ int launch_op(cae_engine* e, int op, const StepArgs& a) {
 
 int launch_one(cae_engine* e, int op, const StepArgs& a) {
     hipStream_t s = e->stream;
+    {   // while profiling: one EMPTY bracket per step = what an event pair itself adds to every bracketed launch
+        ProfScope _cal(e, "event_pair", -1, 0.0);
+    }
     if (op == OP_TRAIN || op == OP_FWDBWD) {
         // the accumulators were zeroed by the previous step's last kernel (k_adam / k_acc_to_f32) or by
         // the caller's zero-filled workspace on the very first step
