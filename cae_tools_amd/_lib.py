@@ -87,7 +87,8 @@ SIGNATURES = {
     "unet_set_step": (C.c_int, [_P, C.c_int64]),
     "unet_set_dataset": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_int64]),
     "unet_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
-    "unet_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "unet_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_double]),
+    "unet_apply_gradients": (C.c_int, [_P, _P]),
     "unet_eval_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
     "unet_score": (C.c_int, [_P, _P, C.c_int, _P]),
     "unet_loss_slots": (C.c_int, [_P]),
@@ -110,7 +111,8 @@ SIGNATURES = {
     "vae_set_step": (C.c_int, [_P, C.c_int64]),
     "vae_set_dataset": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
     "vae_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
-    "vae_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "vae_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_double]),
+    "vae_apply_gradients": (C.c_int, [_P, _P]),
     "vae_eval_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
     "vae_score": (C.c_int, [_P, _P, C.c_int, _P]),
     "vae_loss_slots": (C.c_int, [_P]),
@@ -127,7 +129,8 @@ SIGNATURES = {
     "lin_set_step": (C.c_int, [_P, C.c_int64]),
     "lin_set_dataset": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
     "lin_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
-    "lin_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "lin_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_double]),
+    "lin_apply_gradients": (C.c_int, [_P, _P]),
     "lin_eval_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),
     "lin_score": (C.c_int, [_P, _P, C.c_int, _P]),
     "lin_loss_slots": (C.c_int, [_P]),

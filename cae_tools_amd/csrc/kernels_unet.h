@@ -759,6 +759,10 @@ __global__ void __launch_bounds__(256) k_adamw(long long n, float* __restrict__ 
     }
 }
 
+__global__ void __launch_bounds__(256) k_f32_to_acc(long long n, const float* __restrict__ g32, double* __restrict__ gacc) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) gacc[i] = (double)g32[i];
+}
+
 __global__ void __launch_bounds__(256) k_acc_to_f32(long long n, const double* __restrict__ gacc, float* __restrict__ g32,
                                                     double scale) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)

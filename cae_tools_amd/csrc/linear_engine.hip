@@ -89,7 +89,7 @@ int forward(lin_engine* e, const float* x, int B, float* y) {
 }
 
 int step_common(lin_engine* e, int which, const int32_t* perm, int64_t start, int batch, int slot, bool train, float* grads_out,
-                bool optimise) {
+                bool optimise, double grad_scale = 1.0) {
     if (!e || !e->ws) return lfail(CAE_ERR_STATE, "linear: engine is not bound");
     if (which < 0 || which > 1 || !e->dx[which] || !e->dt[which]) return lfail(CAE_ERR_STATE, "linear: data set %d is not set", which);
     if (batch < 1 || batch > e->max_batch) return lfail(CAE_ERR_ARG, "linear: batch %d outside 1..%d", batch, e->max_batch);
@@ -112,7 +112,7 @@ int step_common(lin_engine* e, int which, const int32_t* perm, int64_t start, in
                            e->gacc() + e->nout * e->nin);
         if (grads_out)
             hipLaunchKernelGGL(k_acc_to_f32, dim3(blocks_for(e->n_params)), dim3(256), 0, e->stream, (long long)e->n_params, e->gacc(),
-                               grads_out, 1.0);
+                               grads_out, grad_scale);
         if (optimise) {
             e->step += 1;
             hipLaunchKernelGGL(vae::k_adam_l2, dim3(blocks_for(e->n_params)), dim3(256), 0, e->stream, (long long)e->n_params, e->params,
@@ -182,9 +182,20 @@ int lin_set_dataset(lin_engine* e, int which, const float* x, const float* targe
 int lin_train_step(lin_engine* e, int which, const int32_t* perm, int64_t start, int batch, int loss_slot) {
     return step_common(e, which, perm, start, batch, loss_slot, true, nullptr, true);
 }
-int lin_forward_backward(lin_engine* e, int which, const int32_t* perm, int64_t start, int batch, int loss_slot, float* grads) {
+int lin_forward_backward(lin_engine* e, int which, const int32_t* perm, int64_t start, int batch, int loss_slot, float* grads,
+                         double grad_scale) {
     if (!grads) return lfail(CAE_ERR_ARG, "lin_forward_backward: null gradient buffer");
-    return step_common(e, which, perm, start, batch, loss_slot, true, grads, false);
+    return step_common(e, which, perm, start, batch, loss_slot, true, grads, false, grad_scale);
+}
+int lin_apply_gradients(lin_engine* e, const float* grads) {
+    if (!e || !e->ws || !grads) return lfail(CAE_ERR_ARG, "lin_apply_gradients: bad argument");
+    hipLaunchKernelGGL(k_f32_to_acc, dim3(blocks_for(e->n_params)), dim3(256), 0, e->stream, (long long)e->n_params, grads, e->gacc());
+    e->step += 1;
+    hipLaunchKernelGGL(vae::k_adam_l2, dim3(blocks_for(e->n_params)), dim3(256), 0, e->stream, (long long)e->n_params, e->params,
+                       e->gacc(), e->m, e->v, e->hyper, (int)e->step);
+    e->gacc_clean = true;
+    LHIP_TRY(hipGetLastError());
+    return CAE_OK;
 }
 int lin_eval_step(lin_engine* e, int which, const int32_t* perm, int64_t start, int batch, int loss_slot) {
     return step_common(e, which, perm, start, batch, loss_slot, false, nullptr, false);

@@ -455,7 +455,8 @@ int gather_x(unet_engine* e, int which, const int32_t* perm, int64_t start, int 
     return CAE_OK;
 }
 
-int train_or_fb(unet_engine* e, int which, const int32_t* perm, int64_t start, int batch, int slot, float* grads_out) {
+int train_or_fb(unet_engine* e, int which, const int32_t* perm, int64_t start, int batch, int slot, float* grads_out,
+                double grad_scale = 1.0) {
     int rc = check_batch(e, which, perm, start, batch, slot);
     if (rc) return rc;
     if ((rc = gather_x(e, which, perm, start, batch))) return rc;
@@ -464,7 +465,7 @@ int train_or_fb(unet_engine* e, int which, const int32_t* perm, int64_t start, i
     if ((rc = backward(e, e->f(e->xb), batch))) return rc;
     if (grads_out) {
         hipLaunchKernelGGL(k_acc_to_f32, dim3(blocks_for(e->n_params, 65536)), dim3(256), 0, e->stream, (long long)e->n_params,
-                           e->gacc(0), grads_out, 1.0);
+                           e->gacc(0), grads_out, grad_scale);
     } else {
         e->step += 1;
         hipLaunchKernelGGL(k_adamw, dim3(blocks_for(e->n_params, 65536)), dim3(256), 0, e->stream, (long long)e->n_params,
@@ -705,10 +706,22 @@ int unet_train_step(unet_engine* e, int which, const int32_t* perm, int64_t star
 }
 
 int unet_forward_backward(unet_engine* e, int which, const int32_t* perm, int64_t start, int batch, int loss_slot,
-                          float* grads) {
+                          float* grads, double grad_scale) {
     if (!grads) return ufail(CAE_ERR_ARG, "unet_forward_backward: null gradient buffer");
     if (e && !e->ds[which & 1].t) return ufail(CAE_ERR_STATE, "unet_forward_backward: data set has no target");
-    return train_or_fb(e, which, perm, start, batch, loss_slot, grads);
+    return train_or_fb(e, which, perm, start, batch, loss_slot, grads, grad_scale);
+}
+
+int unet_apply_gradients(unet_engine* e, const float* grads) {
+    if (!e || !e->ws || !grads) return ufail(CAE_ERR_ARG, "unet_apply_gradients: bad argument");
+    hipLaunchKernelGGL(k_f32_to_acc, dim3(blocks_for(e->n_params, 65536)), dim3(256), 0, e->stream, (long long)e->n_params, grads,
+                       e->gacc(0));
+    e->step += 1;
+    hipLaunchKernelGGL(k_adamw, dim3(blocks_for(e->n_params, 65536)), dim3(256), 0, e->stream, (long long)e->n_params, e->params,
+                       e->gacc(0), e->m, e->v, e->hyper, (int)e->step);
+    e->gacc_clean = true;
+    UHIP_TRY(hipGetLastError());
+    return CAE_OK;
 }
 
 int unet_eval_step(unet_engine* e, int which, const int32_t* perm, int64_t start, int batch, int loss_slot) {

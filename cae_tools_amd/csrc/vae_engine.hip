@@ -329,7 +329,7 @@ int check_batch(vae_engine* e, int which, int64_t start, int batch, int slot, bo
 }
 
 int step_common(vae_engine* e, int which, const int32_t* perm, int64_t start, int batch, int slot, bool train, float* grads_out,
-                bool optimise) {
+                bool optimise, double grad_scale = 1.0) {
     int rc = check_batch(e, which, start, batch, slot, true);
     if (rc) return rc;
     const long long E = (long long)e->in_c * e->in_h * e->in_w;
@@ -346,7 +346,7 @@ int step_common(vae_engine* e, int which, const int32_t* perm, int64_t start, in
         if ((rc = backward(e, e->f(e->xb), batch))) return rc;
         if (grads_out)
             hipLaunchKernelGGL(k_acc_to_f32, dim3(blocks_for(e->n_params)), dim3(256), 0, e->stream, (long long)e->n_params, e->gacc(0),
-                               grads_out, 1.0);
+                               grads_out, grad_scale);
         if (optimise) {
             e->step += 1;
             hipLaunchKernelGGL(vae::k_adam_l2, dim3(blocks_for(e->n_params)), dim3(256), 0, e->stream, (long long)e->n_params, e->params,
@@ -526,9 +526,20 @@ int vae_set_dataset(vae_engine* e, int which, const float* x, const float* targe
 int vae_train_step(vae_engine* e, int which, const int32_t* perm, int64_t start, int batch, int loss_slot) {
     return step_common(e, which, perm, start, batch, loss_slot, true, nullptr, true);
 }
-int vae_forward_backward(vae_engine* e, int which, const int32_t* perm, int64_t start, int batch, int loss_slot, float* grads) {
+int vae_forward_backward(vae_engine* e, int which, const int32_t* perm, int64_t start, int batch, int loss_slot, float* grads,
+                         double grad_scale) {
     if (!grads) return vfail(CAE_ERR_ARG, "vae_forward_backward: null gradient buffer");
-    return step_common(e, which, perm, start, batch, loss_slot, true, grads, false);
+    return step_common(e, which, perm, start, batch, loss_slot, true, grads, false, grad_scale);
+}
+int vae_apply_gradients(vae_engine* e, const float* grads) {
+    if (!e || !e->ws || !grads) return vfail(CAE_ERR_ARG, "vae_apply_gradients: bad argument");
+    hipLaunchKernelGGL(k_f32_to_acc, dim3(blocks_for(e->n_params)), dim3(256), 0, e->stream, (long long)e->n_params, grads, e->gacc(0));
+    e->step += 1;
+    hipLaunchKernelGGL(vae::k_adam_l2, dim3(blocks_for(e->n_params)), dim3(256), 0, e->stream, (long long)e->n_params, e->params,
+                       e->gacc(0), e->m, e->v, e->hyper, (int)e->step);
+    e->gacc_clean = true;
+    VHIP_TRY(hipGetLastError());
+    return CAE_OK;
 }
 int vae_eval_step(vae_engine* e, int which, const int32_t* perm, int64_t start, int batch, int loss_slot) {
     return step_common(e, which, perm, start, batch, loss_slot, false, nullptr, false);

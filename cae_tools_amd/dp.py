@@ -64,6 +64,31 @@ class DataParallel:
         return slot
 
 
+class GradientHalfSteps:
+    """UnetEngine / VaeEngine / LinearEngine behind the three-member interface DataParallel drives: a persistent flat
+    gradient buffer, forward_backward into it with the local/global weight applied in the kernel that narrows the fp64
+    accumulator (grad_scale of *_forward_backward), and the optimiser half-step (*_apply_gradients) after the all-reduce.
+    BatchNorm statistics stay per rank.  The UNET's masked MSE divides by the LOCAL mask count, so with unequal mask
+    coverage across ranks the reduced gradient weights shards by sample count rather than by valid-pixel count."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.grads = torch.zeros(engine.n_param, dtype=torch.float32, device=engine.device)
+        self.stream = engine.stream
+        (self.params, self.exp_avg, self.exp_avg_sq) = (engine.params, engine.exp_avg, engine.exp_avg_sq)
+        self.buffers = getattr(engine, "buffers", None)
+        self._slot = 0
+
+    def forward_backward(self, which, perm, start, size, global_batch):
+        slot = self._slot
+        self._slot = (slot + 1) % self.engine.loss_slots
+        self.engine.forward_backward(which, perm, start, size, slot=slot, global_batch=global_batch, out=self.grads)
+        return slot
+
+    def adam_step(self):
+        self.engine.apply_gradients(self.grads)
+
+
 def shard_bounds(n, world, rank):
     """contiguous split of a global batch of n samples: rank r takes rows [lo, hi) — the union over
     ranks is the reference's single-device batch"""

@@ -139,14 +139,21 @@ class VaeEngine:
         self.steps += 1
         self.num_batches_tracked += 1
 
-    def forward_backward(self, which, perm, start, batch, slot=0):
-        grads = torch.empty(self.n_param, dtype=torch.float32, device=self.device)
+    def forward_backward(self, which, perm, start, batch, slot=0, global_batch=None, out=None):
+        grads = out if out is not None else torch.empty(self.n_param, dtype=torch.float32, device=self.device)
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         check(self.lib.vae_forward_backward(self.handle, which, None if perm is None else perm.data_ptr(), int(start), int(batch),
-                                            int(slot), grads.data_ptr()))
+                                            int(slot), grads.data_ptr(),
+                                            1.0 if global_batch is None else float(batch) / float(global_batch)))
         self.num_batches_tracked += 1
-        self.sync()
+        if out is None:
+            self.sync()
         return grads
+
+    def apply_gradients(self, grads):
+        """optimiser step from a flat fp32 gradient (the data-parallel half-step after the all-reduce)"""
+        check(self.lib.vae_apply_gradients(self.handle, grads.data_ptr()))
+        self.steps += 1
 
     def eval_step(self, which, perm, start, batch, slot=0):
         check(self.lib.vae_eval_step(self.handle, which, None if perm is None else perm.data_ptr(), int(start), int(batch), int(slot)))

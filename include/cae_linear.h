@@ -36,7 +36,10 @@ int lin_set_dataset(lin_engine* e, int which, const float* x_dev, const float* t
 int lin_train_step(lin_engine* e, int which, const int32_t* perm_dev, int64_t start, int batch, int loss_slot);
 /* the same without the optimiser step; fp32 gradient -> grads_dev (lin_param_count floats) */
 int lin_forward_backward(lin_engine* e, int which, const int32_t* perm_dev, int64_t start, int batch, int loss_slot,
-                         float* grads_dev);
+                          float* grads_dev, double grad_scale);
+/* Data parallelism: every rank calls lin_forward_backward with grad_scale = local batch / global batch, the ranks SUM-all-reduce
+ * grads_dev (torch.distributed on the same stream), then each applies the Adam step to the reduced gradient. */
+int lin_apply_gradients(lin_engine* e, const float* grads_dev);
 int lin_eval_step(lin_engine* e, int which, const int32_t* perm_dev, int64_t start, int batch, int loss_slot);
 int lin_score(lin_engine* e, const float* x_dev, int batch, float* y_dev);
 int lin_loss_slots(const lin_engine* e);

@@ -70,7 +70,10 @@ int unet_set_dataset(unet_engine* e, int which, const float* x_dev, const float*
 int unet_train_step(unet_engine* e, int which, const int32_t* perm_dev, int64_t start, int batch, int loss_slot);
 /* The same without the optimiser step: the fp32 gradient of the loss is written to grads_dev (unet_param_count). */
 int unet_forward_backward(unet_engine* e, int which, const int32_t* perm_dev, int64_t start, int batch, int loss_slot,
-                          float* grads_dev);
+                          float* grads_dev, double grad_scale);
+/* Data parallelism: every rank calls unet_forward_backward with grad_scale = local batch / global batch, the ranks SUM-all-reduce
+ * grads_dev (torch.distributed on the same stream), then each applies the AdamW step to the reduced gradient. */
+int unet_apply_gradients(unet_engine* e, const float* grads_dev);
 /* One iteration of __test_epoch (:347-361): eval-mode forward + the two losses -> loss slot. */
 int unet_eval_step(unet_engine* e, int which, const int32_t* perm_dev, int64_t start, int batch, int loss_slot);
 /* UNET.score (:373-382): eval-mode forward of x (batch, Cin, H, W) -> y (batch, Cout, H, W). */

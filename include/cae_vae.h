@@ -48,7 +48,10 @@ int vae_set_dataset(vae_engine* e, int which, const float* x_dev, const float* t
 int vae_train_step(vae_engine* e, int which, const int32_t* perm_dev, int64_t start, int batch, int loss_slot);
 /* the same without the optimiser step: fp32 gradient of the total loss -> grads_dev (vae_param_count floats) */
 int vae_forward_backward(vae_engine* e, int which, const int32_t* perm_dev, int64_t start, int batch, int loss_slot,
-                         float* grads_dev);
+                          float* grads_dev, double grad_scale);
+/* Data parallelism: every rank calls vae_forward_backward with grad_scale = local batch / global batch, the ranks SUM-all-reduce
+ * grads_dev (torch.distributed on the same stream), then each applies the Adam step to the reduced gradient. */
+int vae_apply_gradients(vae_engine* e, const float* grads_dev);
 int vae_eval_step(vae_engine* e, int which, const int32_t* perm_dev, int64_t start, int batch, int loss_slot);
 int vae_score(vae_engine* e, const float* x_dev, int batch, float* y_dev);
 int vae_loss_slots(const vae_engine* e);

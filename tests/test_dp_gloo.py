@@ -105,3 +105,35 @@ def test_two_ranks_match_manual_shard_sum(tmp_path):
         ref.grads.copy_(total)
         ref.adam_step()
     np.testing.assert_allclose(r0.numpy(), ref.flat_params().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_gradient_half_steps_adapter_contract():
+    """GradientHalfSteps hands DataParallel a persistent gradient buffer, rotates loss slots and forwards the
+    local/global weight (host logic only: the engine here records the calls)"""
+    from cae_tools_amd.dp import GradientHalfSteps
+
+    class Recorder:
+        n_param = 5
+        device = torch.device("cpu")
+        stream = None
+        loss_slots = 3
+        params = exp_avg = exp_avg_sq = torch.zeros(5)
+
+        def __init__(self):
+            self.calls = []
+
+        def forward_backward(self, which, perm, start, size, slot=0, global_batch=None, out=None):
+            out.fill_(size / global_batch)
+            self.calls.append(("fb", which, start, size, slot, global_batch, out.data_ptr()))
+
+        def apply_gradients(self, g):
+            self.calls.append(("apply", g.data_ptr(), float(g[0])))
+
+    rec = Recorder()
+    half = GradientHalfSteps(rec)
+    assert half.buffers is None and half.grads.shape == (5,)
+    slots = [half.forward_backward(0, None, 4 * i, 2, 8) for i in range(4)]
+    assert slots == [0, 1, 2, 0]
+    half.adam_step()
+    assert all(c[-1] == half.grads.data_ptr() for c in rec.calls if c[0] == "fb")
+    assert rec.calls[-1] == ("apply", half.grads.data_ptr(), 0.25)
