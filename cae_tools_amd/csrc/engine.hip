@@ -2,6 +2,7 @@
 // and the extern "C" ABI declared in include/cae_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -17,6 +18,7 @@
 #include "kernels_s2.h"
 #include "kernels_gemm.h"
 #include "kernels_igemm.h"
+#include "kernels_head.h"
 
 using namespace cae;
 
@@ -403,14 +405,165 @@ void s2_bwd_dispatch(const ConvLayer& L, const S2Bwd& a, hipStream_t s) {
 #undef ONE
 }
 
+// ---- fused head / tail (kernels_head.h) ----------------------------------------------------------
+
+// Fills the descriptor shared by k_head_fwd and k_tail_bwd and lays out their LDS.  Returns false when the model or
+// the batch does not fit (the caller then runs the per-layer launches).
+bool head_plan(const cae_engine* e, const StepArgs& a, HeadArgs& h, size_t& lds_bytes) {
+    static const int enabled = env_int("CAE_HEAD", 1);   // env: A/B measurements only
+    if (!enabled || !e->use_s2 || a.sync_fn || (int)e->enc.size() > kHeadMaxEnc) return false;
+    memset(&h, 0, sizeof h);
+    h.B = a.batch;
+    h.n_enc = (int)e->enc.size();
+    h.train = a.train ? 1 : 0;
+    h.momentum = kBnMomentum;
+    h.eps = kBnEps;
+    h.st = e->state();
+    h.tiles_per_wg = 4;
+    double* acc = e->gradacc();
+    int64_t top = 0;
+    auto take = [&](int64_t floats) {
+        top = align_up(top, 4);
+        const int64_t o = top;
+        top += floats;
+        return (int)o;
+    };
+    h.o_perm = take(a.batch);
+    int maxc = 1;
+    for (int l = 0; l < h.n_enc; l++) {
+        const ConvLayer& L = e->enc[l];
+        if (L.cout > kHeadMaxC) return false;
+        HeadConv& c = h.enc[l];
+        c.cin = L.cin; c.hin = L.hin; c.win = L.win; c.cout = L.cout; c.hout = L.hout; c.wout = L.wout;
+        c.kh = L.kh; c.kw = L.kw; c.s = L.stride;
+        c.w = e->params + L.w_off; c.bias = e->params + L.b_off;
+        c.gamma = e->params + L.gamma_off; c.beta = e->params + L.beta_off;
+        c.rmean = e->bufs + L.rm_off; c.rvar = e->bufs + L.rv_off; c.saved = e->bn_saved(L.bn_index);
+        c.y = e->fptr(L.act_off); c.g = e->fptr(L.grad_off);
+        {
+            const double count = (double)a.batch * L.hout * L.wout;
+            c.inv_count = 1.0 / count;
+            c.unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
+        }
+        c.w_acc = acc + L.w_off; c.gamma_acc = acc + L.gamma_off; c.beta_acc = acc + L.beta_off;
+        {   // two burst segments: [conv weight .. BatchNorm bias] of the parameter arena, [running mean .. var] of the buffers
+            const int64_t pn = L.beta_off + L.cout - L.w_off, bnn = L.rv_off + L.cout - L.rm_off;
+            if (pn > kHeadThreads || bnn > kHeadThreads || pn <= 0 || bnn <= 0 || h.n_seg + 2 > kHeadMaxSeg) return false;
+            c.o_w = take(pn);
+            c.o_b = c.o_w + (int)(L.b_off - L.w_off);
+            c.o_gamma = c.o_w + (int)(L.gamma_off - L.w_off);
+            c.o_beta = c.o_w + (int)(L.beta_off - L.w_off);
+            c.o_rm = take(bnn);
+            c.o_rv = c.o_rm + (int)(L.rv_off - L.rm_off);
+            h.seg[h.n_seg++] = HeadSeg{e->params + L.w_off, (int)pn, c.o_w, 0};
+            h.seg[h.n_seg++] = HeadSeg{e->bufs + L.rm_off, (int)bnn, c.o_rm, 0};
+        }
+        c.o_c = take(4 * (int64_t)L.cout);
+        if (l + 1 == h.n_enc) c.o_y = take((int64_t)a.batch * L.out_elems());   // inner maps live in the union region
+        if (L.cout > maxc) maxc = L.cout;
+    }
+    int maxd = 0;
+    for (int i = 0; i < 4; i++) {
+        const FcLayer& F = e->fc[i];
+        HeadFc& f = h.fc[i];
+        f.nin = F.nin; f.nout = F.nout; f.relu = F.relu ? 1 : 0;
+        f.w = e->params + F.w_off; f.bias = e->params + F.b_off;
+        f.act = e->fptr(F.act_off); f.grad = e->fptr(F.grad_off);
+        f.w_acc = acc + F.w_off; f.b_acc = acc + F.b_off;
+        if (i < 3 && F.nout > maxd) maxd = F.nout;
+        if (i < 3 && F.nin > maxd) maxd = F.nin;
+    }
+    h.ld_h = (maxd + 31) / 32 * 32 + 2;   // row stride = 2 mod 32 banks: the 16 rows x 2 k of an MFMA operand read do not collide
+    h.o_red = take(2 * 2 * (int64_t)maxc * kHeadWaves);   // doubles
+    h.o_h[0] = take(16 * (int64_t)h.ld_h);
+    h.o_h[1] = take(16 * (int64_t)h.ld_h + 32);   // + guard: an 8-deep k-batch may read up to 30 floats past row 15 (against zero B operands)
+    h.o_part = take(kHeadWaves * 256);
+    {   // union region: the gathered input and the encoder's inner maps while the encoder runs, the Linear weights after
+        // (row stride = 4 mod 32 floats: 16-byte aligned rows, two-way bank conflicts at worst on the operand reads)
+        int64_t wf = 0;
+        int start4 = 0;
+        for (int i = 0; i < 4; i++) {
+            const FcLayer& F = e->fc[i];
+            if (F.nin % 4) return false;   // whole k-steps and 16-byte rows
+            const int rows = i == 3 ? 16 * h.tiles_per_wg : (F.nout + 15) / 16 * 16;
+            HeadW& w = h.wmat[i];
+            w.src = e->params + F.w_off;
+            w.n4row = F.nin / 4;
+            w.ldw = (F.nin + 31) / 32 * 32 + 4;
+            w.start4 = start4;
+            w.strip_floats = i == 3 ? 16 * h.tiles_per_wg * F.nin : 0;
+            w.lds_off = (int)wf;   // relative, rebased below
+            start4 += (i == 3 ? std::min(rows, F.nout) : F.nout) * w.n4row;
+            wf += (int64_t)rows * w.ldw;
+        }
+        wf += 64;   // k-batches read past the last row
+        h.w_total4 = start4;
+        if (h.w_total4 > kHeadW4 * kHeadThreads) return false;
+        int64_t ef = (int64_t)a.batch * e->enc[0].in_elems();
+        for (int l = 0; l + 1 < h.n_enc; l++) ef += align_up((int64_t)a.batch * e->enc[l].out_elems(), 4);
+        const int base = take(std::max(wf, ef));
+        h.o_x = base;
+        int64_t o = base + (int64_t)a.batch * e->enc[0].in_elems();
+        for (int l = 0; l + 1 < h.n_enc; l++) {
+            o = align_up(o, 4);
+            h.enc[l].o_y = (int)o;
+            o += (int64_t)a.batch * e->enc[l].out_elems();
+        }
+        for (int i = 0; i < 4; i++) h.wmat[i].lds_off += base;
+    }
+    for (int i = 0; i < 4; i++) {
+        const int cnt = i == 3 ? 16 * h.tiles_per_wg : e->fc[i].nout;
+        if (cnt > kHeadThreads || h.n_seg + 1 > kHeadMaxSeg) return false;
+        h.o_bias[i] = take(cnt);
+        // Linear 3: a strip of 16 * tiles_per_wg biases per workgroup column; the last strip may read past the vector
+        // (clamped reads inside the parameter arena, masked by the epilogue's n < N)
+        h.seg[h.n_seg++] = HeadSeg{e->params + e->fc[i].b_off, i == 3 ? std::min(cnt, e->fc[3].nout) : cnt, h.o_bias[i], i == 3 ? 1 : 0};
+    }
+    for (int i = 0; i < 4; i++) {
+        if (e->fc[i].nin % 4) return false;   // stage_prefetch walks whole k-steps
+        const int tiles = i == 3 ? h.tiles_per_wg : (e->fc[i].nout + 15) / 16;
+        h.fc_split[i] = stage_split(tiles, e->fc[i].nin);
+    }
+    lds_bytes = (size_t)align_up(top, 4) * sizeof(float);
+    return lds_bytes <= 152 * 1024;
+}
+
+template <class K>
+void head_lds_attr(K kernel, size_t bytes) {
+    static size_t granted = 64 * 1024;
+    if (bytes > granted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        granted = bytes;
+    }
+}
+
 int launch_forward(cae_engine* e, const StepArgs& a) {
     hipStream_t s = e->stream;
     const int B = a.batch;
     const StepState* st = e->state();
     const int act_mode = a.train ? BN_BATCH : BN_RUNNING;
 
+    HeadArgs head;
+    size_t head_lds = 0;
+    const bool fused_head = head_plan(e, a, head, head_lds);
+    if (fused_head) {
+        head.x = a.x_direct ? a.x_direct : e->ds_x[a.which];
+        head.perm = a.x_direct ? nullptr : a.perm;
+        head.use_cursor = a.x_direct ? 0 : 1;
+        head.bump_adam = a.train ? 1 : 0;
+        static const int dbg = env_int("CAE_HEAD_DBG", 0);   // tools/head_phases.py: stamps land in fc[3]'s gradient buffer
+        head.dbg = dbg && !a.train ? reinterpret_cast<long long*>(e->fptr(e->fc[3].grad_off)) : nullptr;
+        const int T = (e->fc[3].nout + 15) / 16;
+        double bytes = 0;
+        for (auto& L : e->enc) bytes += f4((double)B * (L.in_elems() + L.out_elems()));
+        for (int i = 0; i < 4; i++) bytes += f4((double)B * (e->fc[i].nin + e->fc[i].nout) + (double)e->fc[i].nin * e->fc[i].nout);
+        head_lds_attr(k_head_fwd, head_lds);
+        ProfScope _p(e, a.train ? "head_fwd" : "head_eval", 0, bytes);
+        hipLaunchKernelGGL(k_head_fwd, dim3((B + 15) / 16, (T + head.tiles_per_wg - 1) / head.tiles_per_wg), dim3(kHeadThreads),
+                           head_lds, s, head);
+    }
     // ---- encoder convs (encoder.py:40-46)
-    for (size_t l = 0; l < e->enc.size(); l++) {
+    for (size_t l = 0; !fused_head && l < e->enc.size(); l++) {
         const ConvLayer& L = e->enc[l];
         ConvGeom g{B, L.cout, L.hout, L.wout, L.cin, L.hin, L.win, L.kh, L.kw, L.stride};
         Src big;
@@ -439,7 +592,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             if (int rc = sync_bn_table(e, a, L.bn_index)) return rc;
     }
     // ---- encoder_lin / decoder_lin (encoder.py:54-58, decoder.py:31-35)
-    {
+    if (!fused_head) {
         const ConvLayer& P = e->enc.back();
         const int hw = P.hout * P.wout;
         BnDesc bni = bn_of(e, P, act_mode, (double)a.bn_batch * hw, 1);

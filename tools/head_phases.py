@@ -1,0 +1,50 @@
+"""Where the fused encoder+Linear forward kernel (kernels_head.h k_head_fwd) spends its time: wall-clock stamps (100 MHz)
+taken by thread 0 of every workgroup at the phase boundaries, read back from the spare buffer they are written to when
+CAE_HEAD_DBG=1.  Eval-mode forward of one batch, repeated; prints the median per-phase durations in microseconds."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+os.environ["CAE_HEAD_DBG"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from cae_tools_amd.engine import HipEngine                     # noqa: E402
+from cae_tools_amd.models.model_sizer import create_model_spec  # noqa: E402
+
+PHASES = ["prefetch", "bias+zero", "stage inputs", "encoder", "fc0 prologue", "fc0", "fc1", "fc2", "fc3"]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    spec = create_model_spec(input_size=(16, 16), input_channels=1, output_size=(256, 256), output_channels=1)
+    eng = HipEngine(spec, 128, 32, B, device="cuda:0")
+    torch.manual_seed(0)
+    eng.params.normal_(0, 0.05)
+    x = torch.rand((B, 1, 16, 16), device="cuda:0")
+    rows = []
+    inner = []
+    for it in range(20):
+        eng.score(x)
+        eng.sync()
+        raw = eng.debug_read("fcgrad", 3, count=B * 576)
+        full = raw.view(np.int64)[: 36 * 16].reshape(36, 16).astype(np.float64)
+        inner.append(full[:, [2, 9, 10, 12, 13, 3]])
+        st = full[:, :9]
+        rows.append(st)
+    st = np.median(np.stack(rows[5:]), axis=0)
+    d = np.diff(st, axis=1) / 100.0   # 100 MHz -> us
+    print("phase            median over workgroups   workgroup 0")
+    for i, name in enumerate(PHASES[1:]):
+        print(f"{name:16s} {np.median(d[:, i]):8.2f} us            {d[0, i]:8.2f} us")
+    di = np.diff(np.median(np.stack(inner[5:]), axis=0), axis=1) / 100.0
+    for i, name in enumerate(["  conv 0", "  stats 0 + publish", "  in-place act + conv 1", "  stats 1 + publish", "  tail"]):
+        print(f"{name:24s} {np.median(di[:, i]):8.2f} us")
+    print(f"{'first..last':16s} {np.median(st[:, -1] - st[:, 0]) / 100.0:8.2f} us")
+    print(f"launch spread (first stamp, max-min over workgroups): {(st[:, 0].max() - st[:, 0].min()) / 100.0:.2f} us")
+    print(f"whole grid (max last - min first): {(st[:, -1].max() - st[:, 0].min()) / 100.0:.2f} us")
+
+
+if __name__ == "__main__":
+    main()
