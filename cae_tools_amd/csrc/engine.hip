@@ -537,6 +537,70 @@ void head_lds_attr(K kernel, size_t bytes) {
     }
 }
 
+// k_tail_bwd (kernels_head.h): Linear 2..0 backward in one launch.  False: run the per-layer pair launches.
+bool tail_plan(const cae_engine* e, const StepArgs& a, TailArgs& t, size_t& lds_bytes) {
+    static const int enabled = env_int("CAE_TAIL", 1);   // env: A/B measurements only
+    if (!enabled || !e->use_s2 || a.sync_fn) return false;
+    memset(&t, 0, sizeof t);
+    const ConvLayer& P = e->enc.back();
+    double* acc = e->gradacc();
+    t.B = a.batch;
+    for (int i = 0; i < 3; i++) {
+        const FcLayer& F = e->fc[i];
+        if (F.nin % 4 || F.nout % 4) return false;          // 16-byte rows, whole k-steps
+        if (16 * F.nout / 4 > 2 * kHeadThreads) return false;   // a 16-row panel in two loads per thread
+        HeadFc& f = t.fc[i];
+        f.nin = F.nin; f.nout = F.nout; f.relu = F.relu ? 1 : 0;
+        f.w = e->params + F.w_off; f.bias = e->params + F.b_off;
+        f.act = e->fptr(F.act_off); f.grad = e->fptr(F.grad_off);
+        f.w_acc = acc + F.w_off; f.b_acc = acc + F.b_off;
+        t.w4[i] = F.nin * F.nout / 4;
+        if (t.w4[i] > 2 * kHeadThreads) return false;
+        const int r16 = (F.nin + 15) / 16 * 16;
+        t.ldw[i] = r16 % 32 == 0 ? r16 + 16 : r16;   // = 16 mod 32: the four k rows of an operand read land on distinct banks
+    }
+    if (P.cout > kHeadMaxC || e->fc[0].nin != P.cout * P.hout * P.wout) return false;
+    t.y_last = e->fptr(P.act_off);
+    t.g_last = e->fptr(P.grad_off);
+    t.gamma = e->params + P.gamma_off;
+    t.beta = e->params + P.beta_off;
+    t.saved = e->bn_saved(P.bn_index);
+    t.stats = e->bn_stats(P.bn_index);
+    t.C = P.cout;
+    t.hw = P.hout * P.wout;
+    auto ld_of = [](int n) { return (n + 31) / 32 * 32 + 4; };
+    t.ld2 = ld_of(e->fc[2].nout);
+    t.ld1 = ld_of(e->fc[1].nout);
+    t.ld0 = ld_of(e->fc[0].nout);
+    int64_t top = 0;
+    auto take = [&](int64_t floats) {
+        top = align_up(top, 4);
+        const int64_t o = top;
+        top += floats;
+        return (int)o;
+    };
+    t.o_c = take(4 * (int64_t)P.cout);
+    t.o_red = take(2 * 2 * (int64_t)kHeadWaves);
+    t.o_g2 = take(16 * (int64_t)t.ld2 + 32);   // + guard: a k-batch may read a few floats past row 15 (against zero B operands)
+    t.o_g1 = take(16 * (int64_t)t.ld1 + 32);
+    t.o_g0 = take(16 * (int64_t)t.ld0 + 32);
+    top = align_up(top, 4);
+    t.zero4 = (int)((top - t.o_g2) / 4);
+    t.o_y = take(16 * (int64_t)e->fc[0].nin);
+    t.o_gx = take(16 * (int64_t)e->fc[0].nin);
+    int64_t wmax = 0;
+    for (int i = 0; i < 3; i++) wmax = std::max<int64_t>(wmax, (int64_t)e->fc[i].nout * t.ldw[i]);
+    t.o_w = take(wmax + 64);
+    t.o_part = take(kHeadWaves * 256);
+    lds_bytes = (size_t)align_up(top, 4) * sizeof(float);
+    if (lds_bytes > 152 * 1024) return false;
+    // chain (16 rows): g1 (N = fc2.nin, K = fc2.nout), g0 (N = fc1.nin, K = fc1.nout), gx (N = fc0.nin, K = fc0.nout)
+    for (int i = 0; i < 3; i++) t.sp_d[i] = stage_split((e->fc[2 - i].nin + 15) / 16, e->fc[2 - i].nout);
+    // weight-gradient shares: M = nout, N = nin + 1, K = 16 rows
+    for (int i = 0; i < 3; i++) t.sp_w[i] = stage_split(((e->fc[2 - i].nout + 15) / 16) * ((e->fc[2 - i].nin + 16) / 16), 16);
+    return true;
+}
+
 int launch_forward(cae_engine* e, const StepArgs& a) {
     hipStream_t s = e->stream;
     const int B = a.batch;
@@ -891,8 +955,23 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
     {
         const ConvLayer& P = e->enc.back();
         const int hw = P.hout * P.wout;
+        TailArgs tail;
+        size_t tail_lds = 0;
+        const bool fused_tail = tail_plan(e, a, tail, tail_lds);
         for (int i = 3; i >= 0; i--) {
             const FcLayer& F = e->fc[i];
+            if (fused_tail && i == 2) {
+                double bytes = 0;
+                for (int j = 0; j < 3; j++)
+                    bytes += f4((double)B * (3.0 * e->fc[j].nin + 2.0 * e->fc[j].nout) + (double)e->fc[j].nin * e->fc[j].nout) +
+                             8.0 * e->fc[j].nin * e->fc[j].nout;
+                static const int dbg = env_int("CAE_HEAD_DBG", 0);
+                tail.dbg = dbg ? reinterpret_cast<long long*>(e->fptr(e->fc[3].grad_off)) : nullptr;   // Linear 3's gradient is dead by now
+                head_lds_attr(k_tail_bwd, tail_lds);
+                ProfScope _p(e, "tail_bwd", 0, bytes);
+                hipLaunchKernelGGL(k_tail_bwd, dim3((B + 15) / 16, 4), dim3(kHeadThreads), tail_lds, s, tail);
+                break;
+            }
             const float* gout = e->fptr(F.grad_off);
             const float* in = i == 0 ? e->fptr(P.act_off) : e->fptr(e->fc[i - 1].act_off);
             BnDesc bni = i == 0 ? bn_of(e, P, BN_SAVED, 0, 0) : bn_none();

@@ -120,9 +120,9 @@ __device__ __forceinline__ StageCoords stage_coords(StageSplit sp, int K) {
     return c;
 }
 
-template <bool APAD, bool BFAST, class FA, class FB, class FE>
-__device__ __forceinline__ void mfma_stage(int M, int N, int K, int tm0, int TM, int tn0, int TN, StageSplit sp, float* part,
-                                           FA fa, FB fb, FE fe) {
+template <bool APAD, bool BFAST, int DEPTH, class FA, class FB, class FE>
+__device__ __forceinline__ void mfma_stage_d(int M, int N, int K, int tm0, int TM, int tn0, int TN, StageSplit sp, float* part,
+                                             FA fa, FB fb, FE fe) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int tiles = TM * TN;
     const StageCoords c = stage_coords(sp, K);
@@ -136,10 +136,10 @@ __device__ __forceinline__ void mfma_stage(int M, int N, int K, int tm0, int TM,
             const bool am_ok = am < M, bn_ok = bn < N;
             const int s0 = c.kc * c.per, s1 = min(c.S, s0 + c.per);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int st = s0; st < s1; st += 8) {
-                float a[8], b[8];
+            for (int st = s0; st < s1; st += DEPTH) {
+                float a[DEPTH], b[DEPTH];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < DEPTH; u++) {
                     const int k = (st + u) * 4 + q;
                     const bool ok = (st + u) < s1 && k < K;
                     // APAD: the A panel is zero-padded to whole tiles and k-batches (and readable a k-batch past the end)
@@ -154,11 +154,22 @@ __device__ __forceinline__ void mfma_stage(int M, int N, int K, int tm0, int TM,
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+                for (int u = 0; u < DEPTH; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
             }
+            if (sp.lg == 0) {
+                // the wave owns the whole K range of its tile: consume it straight from the accumulator registers
+                // (C/D layout of the 16x16 MFMA: register j of lane l is C[row 4*(l>>4) + j][col l&15])
 #pragma unroll
-            for (int j = 0; j < 4; j++) part[wv * 256 + j * 64 + lane] = acc[j];
+                for (int j = 0; j < 4; j++) {
+                    const int m = tm * 16 + 4 * q + j, n = tn * 16 + r;
+                    if (m < M && n < N) fe(m, n, acc[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) part[wv * 256 + j * 64 + lane] = acc[j];
+            }
         }
+        if (sp.lg == 0) continue;
         __syncthreads();
         const int n_pass = min(c.group, tiles - p0);
         for (int e = threadIdx.x; e < n_pass * 256; e += kHeadThreads) {
@@ -172,25 +183,15 @@ __device__ __forceinline__ void mfma_stage(int M, int N, int K, int tm0, int TM,
         }
         __syncthreads();
     }
+    if (sp.lg == 0) __syncthreads();   // what fe wrote to LDS is visible to the next stage
 }
 
-// sum over taps of in[ky][kx] * w[ky][kx] added to acc (ky outer, as k_down); KS > 0: square kernel known at compile time
-template <int KS>
-__device__ __forceinline__ float head_taps(const float* __restrict__ in, int row_stride, const float* __restrict__ w, int kh,
-                                           int kw, float acc) {
-    if constexpr (KS > 0) {
-        float v[KS * KS];
-#pragma unroll
-        for (int ky = 0; ky < KS; ky++)
-#pragma unroll
-            for (int kx = 0; kx < KS; kx++) v[ky * KS + kx] = in[ky * row_stride + kx];
-#pragma unroll
-        for (int i = 0; i < KS * KS; i++) acc = fmaf(v[i], w[i], acc);
-    } else {
-        for (int ky = 0; ky < kh; ky++)
-            for (int kx = 0; kx < kw; kx++) acc = fmaf(in[ky * row_stride + kx], w[ky * kw + kx], acc);
-    }
-    return acc;
+// k-batches of 8 MFMAs, or of 4 where a wave's share of K is that short (half the operand fetches and MFMAs would be padding)
+template <bool APAD, bool BFAST, class FA, class FB, class FE>
+__device__ __forceinline__ void mfma_stage(int M, int N, int K, int tm0, int TM, int tn0, int TN, StageSplit sp, float* part,
+                                           FA fa, FB fb, FE fe) {
+    if (sp.per <= 4) mfma_stage_d<APAD, BFAST, 4>(M, N, K, tm0, TM, tn0, TN, sp, part, fa, fb, fe);
+    else mfma_stage_d<APAD, BFAST, 8>(M, N, K, tm0, TM, tn0, TN, sp, part, fa, fb, fe);
 }
 
 // fp64 wave sum on the VALU: both halves of the double travel by DPP (the ds_bpermute butterfly costs ~100 cycles a step)
@@ -480,6 +481,232 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(HeadArgs a) {
     run_fc(std::integral_constant<int, 1>{});
     run_fc(std::integral_constant<int, 2>{});
     run_fc(std::integral_constant<int, 3>{});
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_tail_bwd: the backward pass of Linear 2, 1, 0 in one launch (was three k_gemm16_pair launches).
+//
+// grid (row groups of 16 samples, 4 tasks).  Every workgroup walks the input-gradient chain for ITS 16 rows as far as its
+// task needs (a link is ~1.5 us on 16 rows; handing it over through memory would cost more), then adds its rows' share of
+// one weight gradient to the fp64 accumulators (atomics: one add per element per row group):
+//   task 0   g1 = g2 W2, g0 = relu'(h0)(g1 W1), gx = bnrelu'(y)(g0 W0) -> global, + this row group's BatchNorm sums
+//   task 1   g1;      dW1 += g1^T h0
+//   task 2   g1, g0;  dW0 += g0^T bnrelu(y)
+//   task 3            dW2 += g2^T h1
+// g_i = gradient wrt the pre-activation of Linear i's output, [B][nout_i].  One fp32 MFMA pipe per CU (256 FLOP/clk) is what
+// bounds a link, so the rows are spread over workgroups rather than recomputed for the whole batch.  Everything a task
+// reads from global memory is fetched in one burst at its start.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TailArgs {
+    int B;
+    HeadFc fc[3];           // Linear 0..2
+    const float* y_last;    // encoder's last raw conv output [B][C*hw]
+    float* g_last;          // out: masked gradient wrt its BatchNorm output
+    const float *gamma, *beta, *saved;
+    double* stats;          // [kStatShards][C][4]: slots 2, 3 (zero at step start); row group r adds into shard r % kStatShards
+    int C, hw;
+    int ld2, ld1, ld0;      // row strides of the 16-row g2 / g1 / g0 panels
+    int o_g2, o_g1, o_g0, o_y, o_gx, o_w, o_part, o_c, o_red, zero4;   // LDS offsets (floats); zero4 = float4s from o_g2 to clear
+    int ldw[3];             // LDS row strides of W0, W1, W2
+    int w4[3];              // float4s of W0, W1, W2
+    StageSplit sp_d[3];     // chain stages producing g1, g0, gx
+    StageSplit sp_w[3];     // dW2, dW1, dW0
+    long long* dbg;         // diagnostics (tools/head_phases.py): 16 wall-clock stamps per workgroup, or nullptr
+};
+
+// one row-major block [rows][4 * n4row] as coalesced 16-byte loads, at most two per thread
+struct TailRegs {
+    f32x4 v[2];
+};
+__device__ __forceinline__ TailRegs tail_fetch(const float* src, int total4, bool wanted) {
+    TailRegs r;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int idx = min((int)threadIdx.x + j * kHeadThreads, total4 - 1);
+        r.v[j] = wanted ? reinterpret_cast<const f32x4*>(src)[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return r;
+}
+__device__ __forceinline__ void tail_put(const TailRegs& r, float* dst, int total4, int n4row, int ld) {
+    const float inv = 1.0f / (float)n4row;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int idx = (int)threadIdx.x + j * kHeadThreads;
+        if (idx < total4) {
+            const int row = div_small(idx, inv);
+            *reinterpret_cast<f32x4*>(dst + row * ld + 4 * (idx - row * n4row)) = r.v[j];
+        }
+    }
+}
+
+#define TAIL_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
+
+// dW[o][i] += sum over this workgroup's rows of g[b][o] * in(b, i); column nin of `in` is the constant 1 (bias gradient)
+template <class FIN>
+__device__ __forceinline__ void tail_wgrad(const float* g, int ldg, int nin, int nout, StageSplit sp, float* part, FIN in,
+                                           double* accW, double* accB) {
+    // K = the whole 16-row panel: rows past the batch are zero in g, so nothing here needs a predicate
+    mfma_stage<true, true>(nout, nin + 1, 16, 0, (nout + 15) >> 4, 0, (nin + 16) >> 4, sp, part,
+                             [=](int m, int k) { return g[k * ldg + m]; },
+                             [=](int k, int n) { return n == nin ? 1.0f : in(k, n); },
+                             [=](int m, int n, float v) {
+                                 if (n == nin) atomicAdd(&accB[m], (double)v);
+                                 else atomicAdd(&accW[(size_t)m * nin + n], (double)v);
+                             });
+}
+
+// grid (ceil(B / 16), 4), block 1024
+__global__ void __launch_bounds__(kHeadThreads) k_tail_bwd(TailArgs a) {
+    extern __shared__ double lds_d[];
+    float* lds = reinterpret_cast<float*>(lds_d);
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int task = blockIdx.y;
+    const bool need1 = task != 3, need2 = task == 0 || task == 2, need3 = task == 0;
+    const int row0 = blockIdx.x * 16, rows = min(16, a.B - row0);
+    const HeadFc F0 = a.fc[0], F1 = a.fc[1], F2 = a.fc[2];
+
+    TAIL_STAMP(0);
+    // one burst of coalesced loads: this row group's g2; h1 / h0 / y rows, parked in the panel whose masked result they gate
+    // (or, for the task whose weight gradient multiplies them, simply kept there); the weights of the links this task walks
+    const int g4 = rows * (F2.nout >> 2), h14 = rows * (F1.nout >> 2), h04 = rows * (F0.nout >> 2), y4 = rows * (F0.nin >> 2);
+    const bool want_h1 = task == 3 || (need1 && F1.relu), want_h0 = task == 1 || (need2 && F0.relu), want_y = task == 0 || task == 2;
+    const TailRegs rg = tail_fetch(F2.grad + (size_t)row0 * F2.nout, g4, true);
+    const TailRegs rh1 = tail_fetch(F1.act + (size_t)row0 * F1.nout, h14, want_h1);
+    const TailRegs rh0 = tail_fetch(F0.act + (size_t)row0 * F0.nout, h04, want_h0);
+    const TailRegs ry = tail_fetch(a.y_last + (size_t)row0 * F0.nin, y4, want_y);
+    const TailRegs rw2 = tail_fetch(F2.w, a.w4[2], need1);
+    const TailRegs rw1 = tail_fetch(F1.w, a.w4[1], need2);
+    const TailRegs rw0 = tail_fetch(F0.w, a.w4[0], need3);
+    for (int i = tid; i < a.zero4; i += kHeadThreads) reinterpret_cast<f32x4*>(lds + a.o_g2)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4* kc = reinterpret_cast<float4*>(lds + a.o_c);
+    if (tid < a.C) {
+        const float mean = a.saved[2 * tid], invstd = a.saved[2 * tid + 1];
+        kc[tid] = make_float4(mean, a.gamma[tid] * invstd, a.beta[tid], invstd);
+    }
+    __syncthreads();
+    TAIL_STAMP(1);
+    float* g2 = lds + a.o_g2;
+    float* g1 = lds + a.o_g1;
+    float* g0 = lds + a.o_g0;
+    float* ys = lds + a.o_y;   // [16][fc0.nin], dense
+    float* Wb = lds + a.o_w;
+    float* part = lds + a.o_part;
+    const int ld2 = a.ld2, ld1 = a.ld1, ld0 = a.ld0;
+    tail_put(rg, g2, g4, F2.nout >> 2, ld2);
+    if (need1) tail_put(rw2, Wb, a.w4[2], F2.nin >> 2, a.ldw[2]);
+    if (want_h1) tail_put(rh1, g1, h14, F1.nout >> 2, ld1);
+    if (want_h0) tail_put(rh0, g0, h04, F0.nout >> 2, ld0);
+    if (want_y) tail_put(ry, ys, y4, F0.nin >> 2, F0.nin);
+    __syncthreads();
+    TAIL_STAMP(2);
+
+    if (need1)
+    {   // g1[b][i] = relu'(h1) sum_o g2[b][o] W2[o][i]      (decoder.py:31-35 backwards)
+        const int ldw = a.ldw[2], nin = F2.nin, relu = F1.relu;
+        mfma_stage<true, true>(rows, nin, F2.nout, 0, 1, 0, (nin + 15) >> 4, a.sp_d[0], part,
+                               [=](int m, int k) { return g2[m * ld2 + k]; },
+                               [=](int k, int n) { return Wb[k * ldw + n]; },
+                               [=](int m, int n, float v) {
+                                   if (relu) v = g1[m * ld1 + n] > 0.f ? v : 0.f;   // the panel holds h1 until now
+                                   g1[m * ld1 + n] = v;
+                               });
+    }
+    TAIL_STAMP(3);
+    if (need2) {   // g0[b][i] = relu'(h0) sum_o g1[b][o] W1[o][i]      (encoder.py:54-58 backwards)
+        tail_put(rw1, Wb, a.w4[1], F1.nin >> 2, a.ldw[1]);
+        __syncthreads();
+        const int ldw = a.ldw[1], nin = F1.nin, relu = F0.relu;
+        mfma_stage<true, true>(rows, nin, F1.nout, 0, 1, 0, (nin + 15) >> 4, a.sp_d[1], part,
+                               [=](int m, int k) { return g1[m * ld1 + k]; },
+                               [=](int k, int n) { return Wb[k * ldw + n]; },
+                               [=](int m, int n, float v) {
+                                   if (relu) v = g0[m * ld0 + n] > 0.f ? v : 0.f;   // the panel holds h0 until now
+                                   g0[m * ld0 + n] = v;
+                               });
+    }
+    TAIL_STAMP(4);
+    if (need3) {   // gx[b][i] = bnrelu'(y) sum_o g0[b][o] W0[o][i] -> global, and a dense LDS copy for the BatchNorm sums
+        tail_put(rw0, Wb, a.w4[0], F0.nin >> 2, a.ldw[0]);
+        __syncthreads();
+        const int ldw = a.ldw[0], nin = F0.nin, hw = a.hw;
+        const float inv_hw = 1.0f / (float)hw;
+        float* gl = a.g_last + (size_t)row0 * nin;
+        float* gxs = lds + a.o_gx;
+        mfma_stage<true, true>(rows, nin, F0.nout, 0, 1, 0, (nin + 15) >> 4, a.sp_d[2], part,
+                               [=](int m, int k) { return g0[m * ld0 + k]; },
+                               [=](int k, int n) { return Wb[k * ldw + n]; },
+                               [=](int m, int n, float v) {
+                                   const float4 c4 = kc[div_small(n, inv_hw)];
+                                   const float yv = ys[m * nin + n];
+                                   const float gm = fmaf(yv - c4.x, c4.y, c4.z) > 0.f ? v : 0.f;
+                                   gl[(size_t)m * nin + n] = gm;
+                                   gxs[m * nin + n] = gm;
+                               });
+        TAIL_STAMP(5);
+        // this row group's share of dbeta = sum g and dgamma = sum g * xhat per channel (fp64, fixed order): up to 16 channels
+        // at a time, 16 / channels waves each
+        double* red = reinterpret_cast<double*>(lds + a.o_red);
+        const int npos = rows * hw;
+        for (int c0 = 0; c0 < a.C; c0 += kHeadWaves) {
+            const int nc = min(kHeadWaves, a.C - c0);
+            int wpc = 1;
+            while (2 * wpc * nc <= kHeadWaves) wpc *= 2;
+            const int cw = wv / wpc, sub = wv - cw * wpc;   // channel slot and share of this wave
+            double s1 = 0.0, s2 = 0.0;
+            if (cw < nc) {
+                const int c = c0 + cw;
+                const float4 c4 = kc[c];
+                for (int idx = sub * 64 + lane; idx < npos; idx += wpc * 64) {
+                    const int b = div_small(idx, inv_hw), r = idx - b * hw;
+                    const int off = b * nin + c * hw + r;
+                    const float gm = gxs[off];
+                    const float d = ys[off] - c4.x;
+                    s1 += (double)gm;
+                    s2 += (double)gm * (double)(d * c4.w);
+                }
+            }
+            s1 = head_wave_sum(s1);
+            s2 = head_wave_sum(s2);
+            if (lane == 63) {
+                red[wv * 2] = s1;
+                red[wv * 2 + 1] = s2;
+            }
+            __syncthreads();
+            if (tid < nc) {
+                double t1 = 0.0, t2 = 0.0;
+                for (int w = 0; w < wpc; w++) {
+                    t1 += red[(tid * wpc + w) * 2];
+                    t2 += red[(tid * wpc + w) * 2 + 1];
+                }
+                double* row = a.stats + ((size_t)(blockIdx.x & (kStatShards - 1)) * a.C + c0 + tid) * 4;
+                if (gridDim.x <= kStatShards) {
+                    row[2] = t1;
+                    row[3] = t2;
+                } else {
+                    atomicAdd(&row[2], t1);
+                    atomicAdd(&row[3], t2);
+                }
+            }
+            __syncthreads();
+        }
+        TAIL_STAMP(6);
+    }
+    // this row group's share of one weight gradient; the multiplier rows are already in LDS
+    if (task == 3) {
+        tail_wgrad(g2, ld2, F2.nin, F2.nout, a.sp_w[0], part, [=](int k, int n) { return g1[k * ld1 + n]; }, F2.w_acc, F2.b_acc);
+    } else if (task == 1) {
+        tail_wgrad(g1, ld1, F1.nin, F1.nout, a.sp_w[1], part, [=](int k, int n) { return g0[k * ld0 + n]; }, F1.w_acc, F1.b_acc);
+    } else if (task == 2) {
+        const int nin = F0.nin;
+        const float inv_hw = 1.0f / (float)a.hw;
+        tail_wgrad(g0, ld0, nin, F0.nout, a.sp_w[2], part,
+                   [=](int k, int n) {
+                       const float4 c4 = kc[div_small(n, inv_hw)];
+                       return fmaxf(0.f, fmaf(ys[k * nin + n] - c4.x, c4.y, c4.z));
+                   },
+                   F0.w_acc, F0.b_acc);
+    }
+    TAIL_STAMP(7);
 }
 
 }  // namespace cae

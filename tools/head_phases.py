@@ -46,5 +46,38 @@ def main():
     print(f"whole grid (max last - min first): {(st[:, -1].max() - st[:, 0].min()) / 100.0:.2f} us")
 
 
+def tail():
+    """the same for k_tail_bwd: one training step, stamps of row group 0's three task workgroups"""
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    spec = create_model_spec(input_size=(16, 16), input_channels=1, output_size=(256, 256), output_channels=1)
+    eng = HipEngine(spec, 128, 32, B, device="cuda:0", graph=False)
+    torch.manual_seed(0)
+    eng.params.normal_(0, 0.05)
+    eng.set_dataset(0, torch.rand((B, 1, 16, 16), device="cuda:0"), torch.rand((B, 1, 256, 256), device="cuda:0"))
+    groups = (B + 15) // 16
+    rows = []
+    for it in range(20):
+        eng.train_step(0, None, 0, B)
+        eng.sync()
+        raw = eng.debug_read("fcgrad", 3, count=B * 576)
+        rows.append(raw.view(np.int64)[: 4 * groups * 16].reshape(4, groups, 16).astype(np.float64))
+    st = np.median(np.stack(rows[5:]), axis=0)
+    names = ["zero + consts", "panels to LDS", "g1", "g0", "gx", "BatchNorm sums"]
+    print("k_tail_bwd, us per phase; columns = tasks 0 (gx + sums), 1 (dW1), 2 (dW0), 3 (dW2) of row group 0")
+    for i, name in enumerate(names):
+        vals = []
+        for task in range(4):
+            (t0, t1) = (st[task, 0, i], st[task, 0, i + 1])
+            vals.append("    -   " if (t1 <= t0 or t0 == 0) else f"{(t1 - t0) / 100.0:8.2f}")
+        print(f"{name:18s}" + " ".join(vals))
+    last = [6, 3, 4, 2]
+    print(f"{'weight gradient':18s}" + " ".join(f"{(st[t, 0, 7] - st[t, 0, last[t]]) / 100.0:8.2f}" for t in range(4)))
+    print(f"{'workgroup total':18s}" + " ".join(f"{(st[t, 0, 7] - st[t, 0, 0]) / 100.0:8.2f}" for t in range(4)))
+    print(f"whole grid: {(st[:, :, 7].max() - st[:, :, 0].min()) / 100.0:.2f} us")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "tail":
+        tail()
+        sys.exit(0)
     main()
