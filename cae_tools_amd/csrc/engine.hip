@@ -1067,6 +1067,36 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             ain = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
             bna = bn_of(e, P, BN_SAVED, 0, 0);
         }
+        if (l > 0 && e->use_s2 && !a.sync_fn) {
+            // weight gradient and input gradient share only their inputs: one launch (kernels_generic.h k_conv_bwd_pair)
+            const ConvLayer& P = e->enc[l - 1];
+            const int64_t nw = (int64_t)L.cin * L.cout * L.kh * L.kw;
+            const int64_t pos = (int64_t)B * L.hout * L.wout;
+            WgradArgs wa;
+            memset(&wa, 0, sizeof wa);
+            wa.g = g; wa.small = gy; wa.bns = bng; wa.big = ain; wa.bnb = bna;
+            wa.acc = acc + L.w_off;
+            wa.ppb = wgrad_ppb(pos, nw);
+            wa.bg.stats = e->bn_stats(L.bn_index);
+            wa.bg.gamma_acc = acc + L.gamma_off;
+            wa.bg.beta_acc = acc + L.beta_off;
+            wa.bg.C = L.cout;
+            wa.bg.scale = 1.0 / a.world;
+            UpArgs ua;
+            memset(&ua, 0, sizeof ua);
+            ua.g = g; ua.small = gy; ua.bns = bng; ua.w = e->params + L.w_off; ua.bias = nullptr;
+            ua.e = epi_plain(e->fptr(P.grad_off));
+            ua.e.kind = EPI_MASKSTATS;
+            ua.e.stats = e->bn_stats(P.bn_index);
+            ua.e.stats_C = P.cout;
+            ua.e.yprev = e->fptr(P.act_off);
+            ua.bne = bn_of(e, P, BN_SAVED, 0, 0);
+            const int nwy = (int)((pos + wa.ppb - 1) / wa.ppb), ux = grid1((int64_t)B * L.hin * L.win);
+            ProfScope _p(e, "enc_conv_bwd_pair", l, f4((double)B * (3.0 * L.in_elems() + 4.0 * L.out_elems())));
+            hipLaunchKernelGGL(k_conv_bwd_pair, dim3((unsigned)(nw * nwy + (int64_t)ux * L.cin)), dim3(256), lds_bytes(L.cout, L.cin), s,
+                               wa, ua, (int)nw, nwy, ux, st);
+            continue;
+        }
         {
             const int64_t nw = (int64_t)L.cin * L.cout * L.kh * L.kw;
             const int64_t pos = (int64_t)B * L.hout * L.wout;

@@ -260,13 +260,13 @@ __device__ __forceinline__ void epi_element(const Epi& e, const float4* ce, int 
 }
 
 __device__ __forceinline__ void epi_block(const Epi& e, int c, const StepState* st, double r1, double r2,
-                                          double* red) {
+                                          double* red, int bx) {
     if (e.kind == EPI_PLAIN) return;
     if (e.kind == EPI_SIGOUT && !e.target) return;
     const double t1 = block_sum(r1, red);
     const double t2 = (e.kind == EPI_SIGOUT) ? 0.0 : block_sum(r2, red);
     if (threadIdx.x == 0) {
-        const size_t row = ((size_t)(blockIdx.x & (kStatShards - 1)) * e.stats_C + c) * 4;
+        const size_t row = ((size_t)(bx & (kStatShards - 1)) * e.stats_C + c) * 4;
         if (e.kind == EPI_STATS) {
             atomicAdd(&e.stats[row + 0], t1);
             atomicAdd(&e.stats[row + 1], t2);
@@ -274,10 +274,10 @@ __device__ __forceinline__ void epi_block(const Epi& e, int c, const StepState* 
             atomicAdd(&e.stats[row + 2], t1);
             atomicAdd(&e.stats[row + 3], t2);
         } else if (e.kind == EPI_SIGMSE) {
-            atomicAdd(&e.losses[(size_t)st->loss_slot * kStatShards + (blockIdx.x & (kStatShards - 1))], t1);
+            atomicAdd(&e.losses[(size_t)st->loss_slot * kStatShards + (bx & (kStatShards - 1))], t1);
             atomicAdd(&e.bias_acc[c], t2);
         } else {
-            atomicAdd(&e.losses[(size_t)st->loss_slot * kStatShards + (blockIdx.x & (kStatShards - 1))], t1);
+            atomicAdd(&e.losses[(size_t)st->loss_slot * kStatShards + (bx & (kStatShards - 1))], t1);
         }
     }
 }
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(256) k_down(ConvGeom g, Src big, BnDesc bnb, c
         const size_t o = ((size_t)(b * g.Cs + cs) * g.Hs + y) * g.Ws + x;
         epi_element(e, ce, cs, o, 0, acc, r1, r2);
     }
-    epi_block(e, cs, st, r1, r2, red);
+    epi_block(e, cs, st, r1, r2, red, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -334,22 +334,21 @@ __global__ void __launch_bounds__(256) k_down(ConvGeom g, Src big, BnDesc bnb, c
 //                                   T(S[b][cs][(Y-ky)/s][(X-kx)/s]) * w[cs][cl][ky][kx]
 // grid (ceil(B*Hl*Wl/256), Cl)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_up(ConvGeom g, Src small, BnDesc bns, const float* __restrict__ w,
-                                             const float* __restrict__ bias, Epi e, BnDesc bne,
-                                             const StepState* __restrict__ st) {
-    extern __shared__ double lds_d[];
+__device__ __forceinline__ void up_body(const ConvGeom& g, const Src& small, const BnDesc& bns, const float* __restrict__ w,
+                                        const float* __restrict__ bias, const Epi& e, const BnDesc& bne,
+                                        const StepState* __restrict__ st, double* lds_d, const int bx, const int by) {
     double* red = lds_d;
     float4* cs4 = reinterpret_cast<float4*>(lds_d + 4);
     float4* ce = cs4 + g.Cs;
-    const bool designated = blockIdx.x == 0 && blockIdx.y == 0;
+    const bool designated = bx == 0 && by == 0;
     bn_consts(bns, cs4, designated);
     bn_consts(bne, ce, false);
     __syncthreads();
 
-    const int cl = blockIdx.y;
+    const int cl = by;
     const int hw = g.Hl * g.Wl;
     const int n = g.B * hw;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = bx * 256 + threadIdx.x;
     double r1 = 0, r2 = 0;
     if (idx < n) {
         const int b = idx / hw, r = idx - b * hw;
@@ -382,7 +381,14 @@ __global__ void __launch_bounds__(256) k_up(ConvGeom g, Src small, BnDesc bns, c
         }
         epi_element(e, ce, cl, o, tgt, acc, r1, r2);
     }
-    epi_block(e, cl, st, r1, r2, red);
+    epi_block(e, cl, st, r1, r2, red, bx);
+}
+
+__global__ void __launch_bounds__(256) k_up(ConvGeom g, Src small, BnDesc bns, const float* __restrict__ w,
+                                             const float* __restrict__ bias, Epi e, BnDesc bne,
+                                             const StepState* __restrict__ st) {
+    extern __shared__ double lds_d[];
+    up_body(g, small, bns, w, bias, e, bne, st, lds_d, blockIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -399,16 +405,15 @@ struct BnGradOut {
     double scale;  // 1/nranks under SyncBN (the sums are already global), else 1
 };
 
-__global__ void __launch_bounds__(256) k_wgrad(ConvGeom g, Src small, BnDesc bns, Src big, BnDesc bnb,
-                                                double* __restrict__ acc, int ppb, BnGradOut bg,
-                                                const StepState* __restrict__ st) {
-    extern __shared__ double lds_d[];
+__device__ __forceinline__ void wgrad_body(const ConvGeom& g, const Src& small, const BnDesc& bns, const Src& big,
+                                           const BnDesc& bnb, double* __restrict__ acc, int ppb, const BnGradOut& bg,
+                                           const StepState* __restrict__ st, double* lds_d, const int bx, const int by) {
     double* red = lds_d;
     float4* cs4 = reinterpret_cast<float4*>(lds_d + 4);
     float4* cb = cs4 + g.Cs;
     bn_consts(bns, cs4, false);
     bn_consts(bnb, cb, false);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && bg.stats) {
+    if (bx == 0 && by == 0 && bg.stats) {
         for (int c = threadIdx.x; c < bg.C; c += blockDim.x) {
             double sb = 0.0, sg = 0.0;
             for (int sh = 0; sh < kStatShards; sh++) {
@@ -421,7 +426,7 @@ __global__ void __launch_bounds__(256) k_wgrad(ConvGeom g, Src small, BnDesc bns
     }
     __syncthreads();
 
-    int widx = blockIdx.x;
+    int widx = bx;
     const int kx = widx % g.kw;
     widx /= g.kw;
     const int ky = widx % g.kh;
@@ -433,7 +438,7 @@ __global__ void __launch_bounds__(256) k_wgrad(ConvGeom g, Src small, BnDesc bns
 
     const int hw = g.Hs * g.Ws;
     const long long n = (long long)g.B * hw;
-    const long long p0 = (long long)blockIdx.y * ppb;
+    const long long p0 = (long long)by * ppb;
     long long p1 = p0 + ppb;
     if (p1 > n) p1 = n;
     float sum = 0.f;
@@ -449,7 +454,48 @@ __global__ void __launch_bounds__(256) k_wgrad(ConvGeom g, Src small, BnDesc bns
         sum = fmaf(sv, lv, sum);
     }
     const double t = block_sum((double)sum, red);
-    if (threadIdx.x == 0) atomicAdd(&acc[blockIdx.x], t);
+    if (threadIdx.x == 0) atomicAdd(&acc[bx], t);
+}
+
+__global__ void __launch_bounds__(256) k_wgrad(ConvGeom g, Src small, BnDesc bns, Src big, BnDesc bnb,
+                                                double* __restrict__ acc, int ppb, BnGradOut bg,
+                                                const StepState* __restrict__ st) {
+    extern __shared__ double lds_d[];
+    wgrad_body(g, small, bns, big, bnb, acc, ppb, bg, st, lds_d, blockIdx.x, blockIdx.y);
+}
+
+// One launch for a Conv2d layer's weight gradient AND its input gradient (they share only their inputs): workgroups
+// [0, nwx * nwy) are k_wgrad's grid, the rest k_up's (ux wide).
+struct WgradArgs {
+    ConvGeom g;
+    Src small;
+    BnDesc bns;
+    Src big;
+    BnDesc bnb;
+    double* acc;
+    int ppb;
+    BnGradOut bg;
+};
+struct UpArgs {
+    ConvGeom g;
+    Src small;
+    BnDesc bns;
+    const float* w;
+    const float* bias;
+    Epi e;
+    BnDesc bne;
+};
+__global__ void __launch_bounds__(256) k_conv_bwd_pair(WgradArgs wa, UpArgs ua, int nwx, int nwy, int ux,
+                                                        const StepState* __restrict__ st) {
+    extern __shared__ double lds_d[];
+    const int i = blockIdx.x, nw = nwx * nwy;
+    if (i < nw) {
+        const int by = i / nwx;
+        wgrad_body(wa.g, wa.small, wa.bns, wa.big, wa.bnb, wa.acc, wa.ppb, wa.bg, st, lds_d, i - by * nwx, by);
+    } else {
+        const int j = i - nw, by = j / ux;
+        up_body(ua.g, ua.small, ua.bns, ua.w, ua.bias, ua.e, ua.bne, st, lds_d, j - by * ux, by);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
