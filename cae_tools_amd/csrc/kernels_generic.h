@@ -650,13 +650,20 @@ __global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p
                                                float* __restrict__ m, float* __restrict__ v, Hyper h,
                                                const StepState* __restrict__ st, ShardSegs ss, StepTail tl, int t_add) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    // the bias corrections are the same for every element: one lane per workgroup pays for the two fp64 pow()
+    __shared__ float corr[2];
+    if (threadIdx.x == 0) {
+        const int t = st->adam_step + t_add;
+        const double bc1 = 1.0 - pow(h.beta1, (double)t);
+        const double bc2 = 1.0 - pow(h.beta2, (double)t);
+        corr[0] = (float)(h.lr / bc1);
+        corr[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
     if (tl.zero_extra || tl.st) step_tail(tl, i, (long long)gridDim.x * 256);
     if (i >= n) return;
-    const int t = st->adam_step + t_add;
-    const double bc1 = 1.0 - pow(h.beta1, (double)t);
-    const double bc2 = 1.0 - pow(h.beta2, (double)t);
-    const float step_size = (float)(h.lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    const float step_size = corr[0];
+    const float bc2_sqrt = corr[1];
     const float b1 = (float)h.beta1, b2 = (float)h.beta2;
     float g = g32 ? g32[i] : consume_grad(tl, ss, i);
     const float w = p[i];

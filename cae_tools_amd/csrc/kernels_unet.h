@@ -739,10 +739,16 @@ struct Hyper {
 
 __global__ void __launch_bounds__(256) k_adamw(long long n, float* __restrict__ p, double* __restrict__ gacc,
                                                float* __restrict__ m, float* __restrict__ v, Hyper h, int step) {
-    const double bc1 = 1.0 - pow(h.beta1, (double)step);
-    const double bc2 = 1.0 - pow(h.beta2, (double)step);
-    const float step_size = (float)(h.lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    __shared__ float corr[2];   // one lane per workgroup pays for the two fp64 pow() of the bias corrections
+    if (threadIdx.x == 0) {
+        const double bc1 = 1.0 - pow(h.beta1, (double)step);
+        const double bc2 = 1.0 - pow(h.beta2, (double)step);
+        corr[0] = (float)(h.lr / bc1);
+        corr[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const float step_size = corr[0];
+    const float bc2_sqrt = corr[1];
     const float decay = (float)(1.0 - h.lr * h.wd);
     const float b1 = (float)h.beta1, b2 = (float)h.beta2, eps = (float)h.eps;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
