@@ -96,22 +96,28 @@ def roofline_from_profile(recs, steps):
     # between the raw bracket and raw - empty).  Reported, NOT subtracted: `achieved` stays the conservative figure.
     empty = sorted(us for (name, _, us, _) in recs if name == "event_pair")
     overhead = empty[len(empty) // 2] if empty else 0.0
-    agg = {}
-    for (name, layer, us, nbytes) in recs:
+    agg = {}       # per (label, layer): the --table listing
+    by_kernel = {}  # per kernel SYMBOL, as rocprofv3 --stats groups them: the s2_* kernels are template instances per layer
+    for (name, layer, us, nbytes) in recs:  # shape (one symbol per layer), every other label is one symbol for all its layers
         if name == "event_pair":
             continue
         a = agg.setdefault((name, layer), [0.0, 0, nbytes])
         a[0] += us
         a[1] += 1
+        k = by_kernel.setdefault((name, layer) if name.startswith("s2_") else (name, None), [0.0, 0, 0.0])
+        k[0] += us
+        k[1] += 1
+        k[2] += nbytes
     total = sum(a[0] for a in agg.values())
-    (key, (us_sum, count, nbytes)) = max(agg.items(), key=lambda kv: kv[1][0])
-    avg_us = us_sum / count
+    (key, (us_sum, count, bytes_sum)) = max(by_kernel.items(), key=lambda kv: kv[1][0])
+    (avg_us, nbytes) = (us_sum / count, bytes_sum / count)
     achieved = nbytes / (avg_us * 1e-6) / 1e9
     table = sorted(((k[0], k[1], v[0] / v[1], v[2], v[0] / total) for k, v in agg.items()), key=lambda r: -r[4])
+    label = key[0] if key[1] is None else f"{key[0]}[layer {key[1]}]"
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": f"{key[0]}[layer {key[1]}]", "avg_us": avg_us, "empty_event_pair_us": overhead, "algorithmic_bytes_per_launch": nbytes,
-            "share_of_step": us_sum / total}, table, total / steps
+            "kernel": label, "launches_per_step": count / steps, "avg_us": avg_us, "empty_event_pair_us": overhead,
+            "algorithmic_bytes_per_launch": nbytes, "share_of_step": us_sum / total}, table, total / steps
 
 
 def main():
@@ -226,7 +232,12 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                roof["traffic"] = json.load(f).get(roof["kernel"])
+                pmc = json.load(f)
+            if roof["kernel"] in pmc:
+                roof["traffic"] = pmc[roof["kernel"]]
+            else:   # one symbol launched for several layers: the mean over its launches, like `achieved`
+                vals = [v for k, v in pmc.items() if k.startswith(roof["kernel"] + "[")]
+                roof["traffic"] = sum(vals) / len(vals) if vals else None
         result["roofline"] = roof
         result["eager_step_us_sum_of_kernels"] = step_us
         if args.table:

@@ -21,7 +21,7 @@ def _setup(n, seed):
     g = torch.Generator().manual_seed(seed + 1)
     x = torch.rand((n, 1, 16, 16), generator=g)
     t = torch.rand((n, 1, 256, 256), generator=g)
-    eng = HipEngine(spec, 128, 32, max_batch=64)
+    eng = HipEngine(spec, 128, 32, max_batch=max(64, min(n, 160)))
     eng.load_state(enc.state_dict(), dec.state_dict())
     eng.set_hyper(lr=1e-3, weight_decay=1e-5)
     eng.set_dataset(0, x.cuda(), t.cuda())
@@ -29,8 +29,11 @@ def _setup(n, seed):
     return eng, ref, x, t
 
 
-@pytest.mark.parametrize("batch", [64, 36])
+@pytest.mark.parametrize("batch", [64, 36, 160])
 def test_training_step_at_benchmark_size(batch):
+    """64: the benchmark batch (fused encoder+Linear launch, 4 row groups in the fused Linear backward); 36: the reference's
+    ragged last batch (a 4-row group); 160: the encoder no longer fits one workgroup's LDS (per-layer launches) and the
+    Linear backward's ten row groups share the eight BatchNorm sum shards"""
     torch.set_num_threads(8)
     eng, ref, x, t = _setup(batch, 3)
     slot = eng.forward_backward(0, None, 0, batch, batch)
@@ -45,7 +48,9 @@ def test_training_step_at_benchmark_size(batch):
         got = eng.grad_view(k).cpu().numpy()
         scale = float(g.abs().max())
         worst = max(worst, float(np.abs(got - g.numpy()).max()) / scale)
-    assert worst <= 2e-4, worst   # fp32 vs fp32, 112,271 parameters, reductions over 4.2 M pixels
+    # fp32 vs fp32, 112,271 parameters, reductions over 4.2 M pixels (10.5 M at batch 160: 4.0e-4 measured, the same with
+    # the fused launches switched off by CAE_HEAD=0 CAE_TAIL=0)
+    assert worst <= (2e-4 if batch <= 64 else 1e-3), worst
 
 
 def test_scoring_and_properties_at_benchmark_size():
