@@ -19,6 +19,8 @@
 //   wgrad: dw[cs][cl][ky][kx] = sum_b,y,x S[cs][y][x] * L[cl][y*s+ky-p][x*s+kx-p]
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 namespace unet {
@@ -212,30 +214,81 @@ __global__ void __launch_bounds__(256) k_up_thin(Geom g, const float* __restrict
     }
 }
 
+
+// The (b, i) plane of one channel of a (B, C, HW) tensor, walked by a grid (chunks, ...) of 256-thread workgroups: f(b, i)
+// with i a multiple of V, V consecutive elements per visit.  The batch index comes from a 3-instruction fp32 product
+// instead of a 64-bit division where the plane is small enough for that to be exact ((e + 0.5) / d is at least 0.5 / d away
+// from an integer; the product's rounding error is below that while B * HW / V < 2^22).
+template <int V, class F>
+__device__ __forceinline__ void plane_loop(int B, int HW, F f) {
+    const int HWV = HW / V;
+    const long long total = (long long)B * HWV;
+    if (total < (1LL << 22)) {
+        const float inv = 1.0f / (float)HWV;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < (int)total; e += gridDim.x * 256) {
+            const int b = (int)(((float)e + 0.5f) * inv);
+            f(b, (e - b * HWV) * V);
+        }
+    } else {
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+            const long long b = e / HWV;
+            f((int)b, (int)(e - b * HWV) * V);
+        }
+    }
+}
+template <int V>
+struct VecF;
+template <>
+struct VecF<1> {
+    float v[1];
+    __device__ __forceinline__ static VecF ld(const float* p) { return VecF{{*p}}; }
+    __device__ __forceinline__ void st(float* p) const { *p = v[0]; }
+};
+template <>
+struct VecF<4> {
+    float v[4];
+    __device__ __forceinline__ static VecF ld(const float* p) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        return VecF{{t.x, t.y, t.z, t.w}};
+    }
+    __device__ __forceinline__ void st(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+__device__ __forceinline__ bool vec4_ok(int HW, long long s0 = 0, long long s1 = 0, long long s2 = 0) {
+    return ((HW | s0 | s1 | s2) & 3) == 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-channel reductions and BatchNorm (2-d: (B,C,HW); 1-d: HW = 1)
 // ---------------------------------------------------------------------------------------------
 
 // sums[c*sstride + 0..1] += sum x, sum x^2 over (b, i) of x[b*bs + c*HW + i] (the squares only if want_sq).
 // grid (chunks, C)
-__global__ void __launch_bounds__(256) k_chan_sums(const float* __restrict__ x, long long bs, int B, int HW,
-                                                   double* __restrict__ sums, int sstride, int want_sq) {
-    __shared__ double red[4];
+template <int V>
+__device__ __forceinline__ void chan_sums_body(const float* __restrict__ x, long long bs, int B, int HW, double* __restrict__ sums,
+                                               int sstride, int want_sq, double* red) {
     const int c = blockIdx.y;
-    const long long total = (long long)B * HW;
     double s1 = 0, s2 = 0;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long b = e / HW, i = e - b * HW;
-        const double v = (double)x[b * bs + (long long)c * HW + i];
-        s1 += v;
-        s2 += v * v;
-    }
+    plane_loop<V>(B, HW, [&](int b, int i) {
+        const VecF<V> t = VecF<V>::ld(x + b * bs + (long long)c * HW + i);
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            const double v = (double)t.v[j];
+            s1 += v;
+            s2 += v * v;
+        }
+    });
     const double t1 = block_sum(s1, red);
     if (threadIdx.x == 0) atomicAdd(&sums[(size_t)c * sstride], t1);
     if (want_sq) {
         const double t2 = block_sum(s2, red);
         if (threadIdx.x == 0) atomicAdd(&sums[(size_t)c * sstride + 1], t2);
     }
+}
+__global__ void __launch_bounds__(256) k_chan_sums(const float* __restrict__ x, long long bs, int B, int HW,
+                                                   double* __restrict__ sums, int sstride, int want_sq) {
+    __shared__ double red[4];
+    if (vec4_ok(HW, bs)) chan_sums_body<4>(x, bs, B, HW, sums, sstride, want_sq, red);
+    else chan_sums_body<1>(x, bs, B, HW, sums, sstride, want_sq, red);
 }
 
 // a = dropout(relu(bn(z))), s = relu(bn(z)) (optional).  stat_mode 0: mean / invstd from `saved`; 1: running statistics
@@ -272,14 +325,23 @@ __global__ void __launch_bounds__(256) k_bn_act(const float* __restrict__ z, lon
         invstd = saved[2 * c + 1];
     }
     const float sc = invstd * gamma[c], sh = beta[c];
-    const long long total = (long long)B * HW;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long b = e / HW, i = e - b * HW;
-        const float v = fmaxf(fmaf(z[b * zbs + (long long)c * HW + i] - mean, sc, sh), 0.f);
-        const unsigned long long o = ((unsigned long long)b * C + c) * HW + i;
-        if (s_out) s_out[o] = v;
-        if (a_out) a_out[o] = v * drop_factor(d, o);
-    }
+    auto body = [&](auto VT) {
+        constexpr int V = decltype(VT)::value;
+        plane_loop<V>(B, HW, [&](int b, int i) {
+            VecF<V> t = VecF<V>::ld(z + b * zbs + (long long)c * HW + i);
+            const unsigned long long o = ((unsigned long long)b * C + c) * HW + i;
+            VecF<V> a;
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                t.v[j] = fmaxf(fmaf(t.v[j] - mean, sc, sh), 0.f);
+                a.v[j] = t.v[j] * drop_factor(d, o + j);
+            }
+            if (s_out) t.st(s_out + o);
+            if (a_out) a.st(a_out + o);
+        });
+    };
+    if (vec4_ok(HW, zbs)) body(std::integral_constant<int, 4>{});
+    else body(std::integral_constant<int, 1>{});
 }
 
 // backward, pass 1: g = (gA * dropmask + gB) * [bn(z) > 0]; writes g (contiguous), accumulates
@@ -294,21 +356,32 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const float* __restrict__
     const int c = blockIdx.y;
     const float mean = saved[2 * c], invstd = saved[2 * c + 1];
     const float ga = gamma[c], be = beta[c];
-    const long long total = (long long)B * HW;
     double s1 = 0, s2 = 0;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long b = e / HW, i = e - b * HW;
-        const long long ci = (long long)c * HW + i;
-        const float xh = (z[b * zbs + ci] - mean) * invstd;
-        const unsigned long long o = ((unsigned long long)b * C + c) * HW + i;
-        float g = 0.f;
-        if (gA) g = gA[b * gAbs + ci] * drop_factor(d, o);
-        if (gB) g += gB[b * gBbs + ci];
-        if (!(fmaf(xh, ga, be) > 0.f)) g = 0.f;
-        g_out[o] = g;
-        s1 += (double)g;
-        s2 += (double)g * (double)xh;
-    }
+    auto body = [&](auto VT) {
+        constexpr int V = decltype(VT)::value;
+        plane_loop<V>(B, HW, [&](int b, int i) {
+            const long long ci = (long long)c * HW + i;
+            const VecF<V> zt = VecF<V>::ld(z + b * zbs + ci);
+            const unsigned long long o = ((unsigned long long)b * C + c) * HW + i;
+            VecF<V> g, ta, tb;
+            if (gA) ta = VecF<V>::ld(gA + b * gAbs + ci);
+            if (gB) tb = VecF<V>::ld(gB + b * gBbs + ci);
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                const float xh = (zt.v[j] - mean) * invstd;
+                float gv = 0.f;
+                if (gA) gv = ta.v[j] * drop_factor(d, o + j);
+                if (gB) gv += tb.v[j];
+                if (!(fmaf(xh, ga, be) > 0.f)) gv = 0.f;
+                g.v[j] = gv;
+                s1 += (double)gv;
+                s2 += (double)gv * (double)xh;
+            }
+            g.st(g_out + o);
+        });
+    };
+    if (vec4_ok(HW, zbs, gA ? gAbs : 0, gB ? gBbs : 0)) body(std::integral_constant<int, 4>{});
+    else body(std::integral_constant<int, 1>{});
     const double t1 = block_sum(s1, red);
     const double t2 = block_sum(s2, red);
     if (threadIdx.x == 0) {
@@ -332,13 +405,22 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(float* __restrict__ g, con
         acc_gamma[c] += sums[2 * c + 1];
         acc_beta[c] += sums[2 * c];
     }
-    const long long total = (long long)B * HW;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long b = e / HW, i = e - b * HW;
-        const float xh = (z[b * zbs + (long long)c * HW + i] - mean) * invstd;
-        const long long o = (b * C + c) * HW + i;
-        g[o] = k1 * (g[o] - m1 - xh * m2);
-    }
+    auto body = [&](auto VT) {
+        constexpr int V = decltype(VT)::value;
+        plane_loop<V>(B, HW, [&](int b, int i) {
+            const VecF<V> zt = VecF<V>::ld(z + b * zbs + (long long)c * HW + i);
+            const long long o = ((long long)b * C + c) * HW + i;
+            VecF<V> gt = VecF<V>::ld(g + o);
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                const float xh = (zt.v[j] - mean) * invstd;
+                gt.v[j] = k1 * (gt.v[j] - m1 - xh * m2);
+            }
+            gt.st(g + o);
+        });
+    };
+    if (vec4_ok(HW, zbs)) body(std::integral_constant<int, 4>{});
+    else body(std::integral_constant<int, 1>{});
 }
 
 // g *= dropmask * [h > 0]  (ReLU + dropout backward where there is no BatchNorm: the second Linear of each stack)
@@ -440,16 +522,23 @@ __global__ void __launch_bounds__(256) k_scale_concat(const float* __restrict__ 
     const bool first = c2 < C;
     const int c = first ? c2 : c2 - C;
     const float* src = first ? u : skip;
-    const long long total = (long long)B * HW;
     double s1 = 0, s2 = 0;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long b = e / HW, i = e - b * HW;
-        float v = src[(b * C + c) * HW + i];
-        if (first) v *= att[b * C + c];
-        cat[(b * 2 * C + c2) * HW + i] = v;
-        s1 += (double)v;
-        s2 += (double)v * (double)v;
-    }
+    auto body = [&](auto VT) {
+        constexpr int V = decltype(VT)::value;
+        plane_loop<V>(B, HW, [&](int b, int i) {
+            VecF<V> t = VecF<V>::ld(src + ((long long)b * C + c) * HW + i);
+            const float k = first ? att[(long long)b * C + c] : 1.f;
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                if (first) t.v[j] *= k;
+                s1 += (double)t.v[j];
+                s2 += (double)t.v[j] * (double)t.v[j];
+            }
+            t.st(cat + ((long long)b * 2 * C + c2) * HW + i);
+        });
+    };
+    if (vec4_ok(HW)) body(std::integral_constant<int, 4>{});
+    else body(std::integral_constant<int, 1>{});
     if (sums) {
         const double t1 = block_sum(s1, red);
         const double t2 = block_sum(s2, red);
@@ -530,17 +619,27 @@ __global__ void __launch_bounds__(256) k_scale_bwd(const float* __restrict__ dca
                                                    int C, int HW, float* __restrict__ du, double* __restrict__ accb) {
     __shared__ double red[4];
     const int c = blockIdx.y;
-    const long long total = (long long)B * HW;
     const float inv = 1.f / (float)HW;
     double s = 0;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long b = e / HW, i = e - b * HW;
-        const long long bc = b * C + c;
-        float v = dcat[(b * 2 * C + c) * HW + i] * att[bc] + dpool[2 * bc] * inv;
-        if ((int)i == __float_as_int(pool[3 * bc + 2])) v += dpool[2 * bc + 1];
-        du[bc * HW + i] = v;
-        s += (double)v;
-    }
+    auto body = [&](auto VT) {
+        constexpr int V = decltype(VT)::value;
+        plane_loop<V>(B, HW, [&](int b, int i) {
+            const long long bc = (long long)b * C + c;
+            VecF<V> t = VecF<V>::ld(dcat + ((long long)b * 2 * C + c) * HW + i);
+            const float ka = att[bc], kp = dpool[2 * bc] * inv;
+            const int imax = __float_as_int(pool[3 * bc + 2]);
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                float v = t.v[j] * ka + kp;
+                if (i + j == imax) v += dpool[2 * bc + 1];
+                t.v[j] = v;
+                s += (double)v;
+            }
+            t.st(du + bc * HW + i);
+        });
+    };
+    if (vec4_ok(HW)) body(std::integral_constant<int, 4>{});
+    else body(std::integral_constant<int, 1>{});
     const double t = block_sum(s, red);
     if (threadIdx.x == 0 && accb) atomicAdd(&accb[c], t);
 }
