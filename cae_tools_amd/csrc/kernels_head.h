@@ -92,10 +92,6 @@ struct HeadArgs {
 // share the tiles; with fewer tiles than waves the waves split K and the partial tiles are summed through LDS in a fixed
 // order.  fa / fb fetch one operand element (they are only called for in-range indices), fe(m, n, value) consumes C.
 // All threads of the workgroup must call mfma_stage (it synchronises).
-// n / d for 0 <= n < 2^22 and d < 8000 with inv_d = 1.0f / d: (n + 0.5) / d is at least 0.5 / d away from an integer,
-// far more than the rounding error of the fp32 product (3 instructions instead of the ~40 of an integer division)
-__device__ __forceinline__ int div_small(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
-
 inline StageSplit stage_split(int tiles, int K) {
     const int S = (K + 3) / 4;
     int lg = 0;

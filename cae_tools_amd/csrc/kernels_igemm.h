@@ -179,6 +179,8 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
     const bool b_ok = ci < a.Cin;
     const float* bp = a.w + (size_t)ci * K;
     const int khw = a.KH * a.KW;
+    const bool fastdiv = K < kDivSmallMaxN && khw < kDivSmallMaxD;
+    const float inv_khw = 1.0f / (float)khw;
     float d1 = 0.f, d2 = 0.f;
 
     const int KS = a.ksplit;
@@ -206,7 +208,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
                     const size_t off = abase + koff[k];
                     v = a.g[off];
                     if (a.bn_out.mode == BN_BWD) {
-                        const float4 c4 = cout4[k / khw];
+                        const float4 c4 = cout4[fastdiv ? div_small(k, inv_khw) : k / khw];
                         v = c4.y * v - c4.z - (a.yout[off] - c4.x) * c4.w;
                     }
                 }
@@ -321,6 +323,8 @@ __device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, co
     const int per = (s_end - s_begin + 3) >> 2;
     const int s0 = s_begin + wv * per, s1 = min(s_end, s0 + per);
 
+    const bool fastdiv = K < kDivSmallMaxN && HW < kDivSmallMaxD;
+    const float inv_hw = 1.0f / (float)HW, inv_w = 1.0f / (float)a.W;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int st = s0; st < s1; st += 8) {
         float av[8], bv[8];
@@ -328,8 +332,15 @@ __device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, co
         for (int u = 0; u < 8; u++) {
             const int k = (st + u) * 4 + q;
             const bool k_ok = (st + u) < s1 && k < K;
-            const int b = k / HW, pos = k - b * HW;
-            const int y = pos / a.W, x = pos - y * a.W;
+            int b, y;
+            if (fastdiv) {   // two integer divisions per operand element were most of this loop's instructions
+                b = div_small(k, inv_hw);
+                y = div_small(k - b * HW, inv_w);
+            } else {
+                b = k / HW;
+                y = (k - b * HW) / a.W;
+            }
+            const int pos = k - b * HW, x = pos - y * a.W;
             float va = 0.f, vb = 0.f;
             if (a_ok && k_ok) {
                 va = a.ain[((size_t)b * a.Cin + ci) * HW + pos];
