@@ -584,10 +584,12 @@ bool tail_plan(const cae_engine* e, const StepArgs& a, TailArgs& t, size_t& lds_
     t.o_g2 = take(16 * (int64_t)t.ld2 + 32);   // + guard: a k-batch may read a few floats past row 15 (against zero B operands)
     t.o_g1 = take(16 * (int64_t)t.ld1 + 32);
     t.o_g0 = take(16 * (int64_t)t.ld0 + 32);
+    // y and gx sit inside the cleared region too: the weight-gradient stage reads all 16 panel rows without predicates, and
+    // rows past the batch must be finite (they meet zero gradient rows; LDS garbage could be NaN)
+    t.o_y = take(16 * (int64_t)e->fc[0].nin + 32);
+    t.o_gx = take(16 * (int64_t)e->fc[0].nin + 32);
     top = align_up(top, 4);
     t.zero4 = (int)((top - t.o_g2) / 4);
-    t.o_y = take(16 * (int64_t)e->fc[0].nin);
-    t.o_gx = take(16 * (int64_t)e->fc[0].nin);
     int64_t wmax = 0;
     for (int i = 0; i < 3; i++) wmax = std::max<int64_t>(wmax, (int64_t)e->fc[i].nout * t.ldw[i]);
     t.o_w = take(wmax + 64);
@@ -903,8 +905,12 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             const size_t lds_w = 1024 * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4);
             ProfScope _p(e, "ig_convt_bwd_pair", l,
                          f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));
-            hipLaunchKernelGGL(k_ig_bwd_pair, dim3(wtiles * chunks + d_gx * d_gy), dim3(256), lds_d > lds_w ? lds_d : lds_w, s,
-                               fw, fd, wtiles, chunks, d_gx);
+            // XCD-aware order (kernels_igemm.h): d_group input-gradient blocks cover the positions of one weight-gradient chunk
+            int d_group = (per * 4) / (per_block * 16);
+            if (d_group < 1) d_group = 1;
+            const int w_n8 = (chunks + 7) / 8, d_n8 = ((d_gx + d_group - 1) / d_group + 7) / 8;
+            hipLaunchKernelGGL(k_ig_bwd_pair, dim3(8 * wtiles * w_n8 + 8 * d_n8 * d_group * d_gy), dim3(256),
+                               lds_d > lds_w ? lds_d : lds_w, s, fw, fd, wtiles, chunks, w_n8, d_gx, d_gy, d_group);
             if (l > 0)
                 if (int rc = sync_bn_table(e, a, e->dec[l - 1].bn_index)) return rc;
             continue;

@@ -384,12 +384,28 @@ __global__ void __launch_bounds__(256) k_ig_wgrad(IgWgrad a) {
 
 // weight gradient and input gradient of one layer in a single launch: workgroups [0, nw) are the
 // (tile, K-chunk) grid of the weight gradient, the rest the (M-tile, Cin-tile) grid of the input gradient
-__global__ void __launch_bounds__(256) k_ig_bwd_pair(IgWgrad w, IgDgrad d, int w_gx, int w_gy, int d_gx) {
+//
+// XCD-aware block order.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2, and both halves read the same
+// gradient map: a weight-gradient K chunk (w.ksteps_per_block * 4 input positions, all its tiles) and the input-gradient
+// blocks of the same positions (d_group of them, all Cin tiles) are given ids with the same id % 8, so one XCD's L2 fetches
+// a slice of the gradient / activation maps once instead of every L2 fetching most of it.
+// grid = ig_pair_blocks(...): w_n8 = ceil(chunks / 8), d_n8 = ceil(ceil(d_gx / d_group) / 8).
+__global__ void __launch_bounds__(256) k_ig_bwd_pair(IgWgrad w, IgDgrad d, int w_tiles, int w_chunks, int w_n8, int d_gx,
+                                                      int d_gy, int d_group) {
     extern __shared__ double lds_d[];
-    const int nw = w_gx * w_gy;
-    const int id = blockIdx.x;
-    if (id < nw) ig_wgrad_body(w, id % w_gx, id / w_gx, lds_d);
-    else ig_dgrad_body(d, (id - nw) % d_gx, (id - nw) / d_gx, lds_d);
+    const int nw = 8 * w_tiles * w_n8;
+    const int id = blockIdx.x, x = id & 7;
+    if (id < nw) {
+        const int j = id >> 3, cx = j / w_tiles;
+        const int chunk = cx * 8 + x;
+        if (chunk < w_chunks) ig_wgrad_body(w, j - cx * w_tiles, chunk, lds_d);
+    } else {
+        const int j = (id - nw) >> 3;   // nw is a multiple of 8: (id - nw) & 7 == x
+        const int by = j % d_gy, t = j / d_gy;
+        const int sub = t % d_group, cx = t / d_group;
+        const int bx = (cx * 8 + x) * d_group + sub;
+        if (bx < d_gx) ig_dgrad_body(d, bx, by, lds_d);
+    }
 }
 
 }  // namespace cae
