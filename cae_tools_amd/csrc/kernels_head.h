@@ -95,7 +95,10 @@ struct HeadArgs {
 inline StageSplit stage_split(int tiles, int K) {
     const int S = (K + 3) / 4;
     int lg = 0;
-    while ((2 << lg) * tiles <= kHeadWaves && (2 << lg) <= S) lg++;
+    // splitting K costs an LDS round trip of the partial tiles and two barriers (~700 cycles, about 20 MFMA k-steps): only
+    // worth it for long contractions on few tiles; otherwise each wave keeps a whole tile and consumes it from registers
+    if (S >= 24 && tiles <= 4)
+        while ((2 << lg) * tiles <= kHeadWaves && (2 << lg) <= S) lg++;
     StageSplit r;
     r.lg = lg;
     r.per = (S + (1 << lg) - 1) >> lg;
