@@ -134,13 +134,29 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-    // the per-lane partials are sums of a few hundred fp32 terms: split into hi + lo floats, reduce
-    // both with DPP in fp32 pairs would lose the point of fp64; use the 64-bit DPP-free butterfly on
-    // two 32-bit halves instead
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// fp64 wave sum on the VALU: both halves of the double travel by DPP (the ds_bpermute butterfly costs ~100 cycles a step)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROW_MASK, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+// valid in lane 63 only
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+    v += dpp_d<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);       // row_half_mirror
+    v += dpp_d<0x140>(v);       // row_mirror
+    v += dpp_d<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_d<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
     return v;
+}
+// valid in every lane
+__device__ __forceinline__ double wave_sum(double v) {
+    const long long bits = __builtin_bit_cast(long long, wave_sum_lane63(v));
+    const int lo = __builtin_amdgcn_readlane((int)bits, 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
 // sum of v over the block, valid in thread 0.  red: LDS scratch of >= blockDim/64 doubles.

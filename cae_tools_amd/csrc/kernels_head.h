@@ -193,24 +193,8 @@ __device__ __forceinline__ void mfma_stage(int M, int N, int K, int tm0, int TM,
     else mfma_stage_d<APAD, BFAST, 8>(M, N, K, tm0, TM, tn0, TN, sp, part, fa, fb, fe);
 }
 
-// fp64 wave sum on the VALU: both halves of the double travel by DPP (the ds_bpermute butterfly costs ~100 cycles a step)
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ double dpp_d(double v) {
-    const long long bits = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, ROW_MASK, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROW_MASK, 0xF, true);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
-}
-// valid in lane 63
-__device__ __forceinline__ double head_wave_sum(double v) {
-    v += dpp_d<0xB1>(v);
-    v += dpp_d<0x4E>(v);
-    v += dpp_d<0x141>(v);
-    v += dpp_d<0x140>(v);
-    v += dpp_d<0x142, 0xA>(v);
-    v += dpp_d<0x143, 0xC>(v);
-    return v;
-}
+// fp64 wave sum, valid in lane 63 (kernels_generic.h)
+__device__ __forceinline__ double head_wave_sum(double v) { return wave_sum_lane63(v); }
 
 // Everything small the kernel reads from global memory (encoder parameters and running statistics, Linear biases), copied
 // to LDS in ONE burst of loads: one element per thread per segment, all loads issued before the first store.  The sample

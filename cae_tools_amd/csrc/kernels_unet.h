@@ -27,12 +27,24 @@ namespace unet {
 namespace {   // internal linkage: this header is compiled into more than one translation unit
 
 // sum of v over the block (any multiple of 64 threads), valid in thread 0.  red: LDS scratch of blockDim/64 doubles.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROW_MASK, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
 __device__ __forceinline__ double block_sum(double v, double* red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    // fp64 wave sum on the VALU (DPP moves of both halves; the ds_bpermute butterfly costs ~100 cycles a step): lane 63
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    v += dpp_d<0x140>(v);
+    v += dpp_d<0x142, 0xA>(v);
+    v += dpp_d<0x143, 0xC>(v);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __syncthreads();
-    if (lane == 0) red[wv] = v;
+    if (lane == 63) red[wv] = v;
     __syncthreads();
     double t = 0;
     if (threadIdx.x == 0)
