@@ -376,16 +376,17 @@ __device__ __forceinline__ void up_body(const ConvGeom& g, const Src& small, con
         const int Y = r / g.Wl, X = r - Y * g.Wl;
         const size_t sb = sample_of(small.perm, small.use_cursor, st, b);
         float acc = bias ? bias[cl] : 0.f;
-        const int ky0 = Y % g.s, kx0 = X % g.s;
+        // taps of output (Y, X): ky = Y mod s, + s, ... reading row y = Y / s, - 1, ...: one division per dimension per
+        // thread instead of one per (channel, tap)
+        const int y0 = Y / g.s, x0 = X / g.s;
+        const int ky0 = Y - y0 * g.s, kx0 = X - x0 * g.s;
         for (int cs = 0; cs < g.Cs; cs++) {
             const float* wp = w + (size_t)(cs * g.Cl + cl) * g.kh * g.kw;
             const size_t base = (sb * g.Cs + cs) * (size_t)g.Hs * g.Ws;
             const float4 k = bns.mode ? cs4[cs] : make_float4(0, 0, 0, 0);
-            for (int ky = ky0; ky < g.kh && ky <= Y; ky += g.s) {
-                const int y = (Y - ky) / g.s;
+            for (int ky = ky0, y = y0; ky < g.kh && y >= 0; ky += g.s, y--) {
                 if (y >= g.Hs) continue;
-                for (int kx = kx0; kx < g.kw && kx <= X; kx += g.s) {
-                    const int x = (X - kx) / g.s;
+                for (int kx = kx0, x = x0; kx < g.kw && x >= 0; kx += g.s, x--) {
                     if (x >= g.Ws) continue;
                     const size_t off = base + (size_t)y * g.Ws + x;
                     const float v = small.p[off];
@@ -463,9 +464,18 @@ __device__ __forceinline__ void wgrad_body(const ConvGeom& g, const Src& small, 
     long long p1 = p0 + ppb;
     if (p1 > n) p1 = n;
     float sum = 0.f;
+    const bool fastdiv = n < kDivSmallMaxN && hw < kDivSmallMaxD;   // 3-instruction index arithmetic instead of 64-bit divisions
+    const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)g.Ws;
     for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
-        const int b = (int)(p / hw), r = (int)(p - (long long)b * hw);
-        const int y = r / g.Ws, x = r - y * g.Ws;
+        int b, y;
+        if (fastdiv) {
+            b = div_small((int)p, inv_hw);
+            y = div_small((int)p - b * hw, inv_w);
+        } else {
+            b = (int)(p / hw);
+            y = (int)(p - (long long)b * hw) / g.Ws;
+        }
+        const int r = (int)(p - (long long)b * hw), x = r - y * g.Ws;
         const size_t ss = sample_of(small.perm, small.use_cursor, st, b);
         const size_t sl = sample_of(big.perm, big.use_cursor, st, b);
         const size_t so = ((ss * g.Cs + cs) * (size_t)g.Hs + y) * g.Ws + x;
