@@ -183,6 +183,8 @@ BnDesc bn_of(const cae_engine* e, const ConvLayer& L, int mode, double count, in
     d.rvar = e->bufs + L.rv_off;
     d.saved = e->bn_saved(L.bn_index);
     d.count = count;
+    d.inv_count = count > 0.0 ? 1.0 / count : 0.0;
+    d.unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
     d.momentum = kBnMomentum;
     d.eps = kBnEps;
     d.update = update;

@@ -73,6 +73,7 @@ struct BnDesc {
     float* rvar;
     float* saved;  // [C][2]: mean, invstd
     double count;  // elements per channel (global count under SyncBN)
+    double inv_count, unbias;   // 1 / count and count / (count - 1) (1 for a single element): no fp64 divisions on the device
     float momentum;
     float eps;
     int update;    // BN_BATCH: this consumer also updates running stats and `saved`
@@ -187,15 +188,17 @@ __device__ __forceinline__ void bn_consts(const BnDesc& d, float4* out, bool des
                 s1 += d.stats[((size_t)sh * d.C + c) * 4];
                 s2 += d.stats[((size_t)sh * d.C + c) * 4 + 1];
             }
-            const double m = s1 / d.count;
-            double var = s2 / d.count - m * m;
+            // every consumer's prologue runs this on its critical path: multiplications by host-computed reciprocals and
+            // an fp32 square root instead of three fp64 divisions and an fp64 square root
+            const double m = s1 * d.inv_count;
+            double var = s2 * d.inv_count - m * m;
             var = var < 0.0 ? 0.0 : var;
             mean = (float)m;
-            invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+            invstd = 1.0f / sqrtf((float)(var + (double)d.eps));
             if (designated && d.update) {
                 d.saved[2 * c] = mean;
                 d.saved[2 * c + 1] = invstd;
-                const double unb = d.count > 1.0 ? var * (d.count / (d.count - 1.0)) : var;
+                const double unb = var * d.unbias;
                 d.rmean[c] = (1.f - d.momentum) * d.rmean[c] + d.momentum * mean;
                 d.rvar[c] = (1.f - d.momentum) * d.rvar[c] + d.momentum * (float)unb;
             }
@@ -213,8 +216,8 @@ __device__ __forceinline__ void bn_consts(const BnDesc& d, float4* out, bool des
                 dbeta += d.stats[((size_t)sh * d.C + c) * 4 + 2];
                 dgamma += d.stats[((size_t)sh * d.C + c) * 4 + 3];
             }
-            const float k2 = (float)((double)scale * dbeta / d.count);
-            const float k3 = (float)((double)scale * (double)invstd * dgamma / d.count);
+            const float k2 = (float)((double)scale * dbeta * d.inv_count);
+            const float k3 = (float)((double)scale * (double)invstd * dgamma * d.inv_count);
             out[c] = make_float4(mean, scale, k2, k3);
         } else {
             out[c] = make_float4(mean, scale, d.beta[c], invstd);
