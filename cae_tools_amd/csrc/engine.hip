@@ -773,7 +773,8 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             // at most ~1024 workgroups over the 4 parities: every workgroup ends with up to 32 fp64 atomics
             {
                 const int waves_m = 4 / f.ksplit;
-                int tpw = (mtiles * 4 + waves_m * 1024 - 1) / (waves_m * 1024);
+                static const int target = env_int("CAE_IG_FWD_WGS", 1024);   // env: tuning only
+                int tpw = (mtiles * 4 + waves_m * target - 1) / (waves_m * target);
                 f.tiles_per_wave = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
             }
             const int per_block = (4 / f.ksplit) * f.tiles_per_wave;
@@ -875,7 +876,8 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             }
             const int wtiles = ((L.cin + 15) / 16) * ((L.cout * L.kh * L.kw + 15) / 16);
             const int steps = (B * L.hin * L.win + 3) / 4;
-            int chunks = 2048 / wtiles;
+            static const int wgrad_target = env_int("CAE_IG_WGRAD_WGS", 2048);   // env: tuning only
+            int chunks = wgrad_target / wtiles;
             if (chunks < 1) chunks = 1;
             int per = (steps + chunks - 1) / chunks;
             per = (per + 31) / 32 * 32;
