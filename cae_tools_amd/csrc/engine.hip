@@ -441,13 +441,12 @@ bool head_plan(const cae_engine* e, const StepArgs& a, HeadArgs& h, size_t& lds_
         c.w = e->params + L.w_off; c.bias = e->params + L.b_off;
         c.gamma = e->params + L.gamma_off; c.beta = e->params + L.beta_off;
         c.rmean = e->bufs + L.rm_off; c.rvar = e->bufs + L.rv_off; c.saved = e->bn_saved(L.bn_index);
-        c.y = e->fptr(L.act_off); c.g = e->fptr(L.grad_off);
+        c.y = e->fptr(L.act_off);
         {
             const double count = (double)a.batch * L.hout * L.wout;
             c.inv_count = 1.0 / count;
             c.unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
         }
-        c.w_acc = acc + L.w_off; c.gamma_acc = acc + L.gamma_off; c.beta_acc = acc + L.beta_off;
         {   // two burst segments: [conv weight .. BatchNorm bias] of the parameter arena, [running mean .. var] of the buffers
             const int64_t pn = L.beta_off + L.cout - L.w_off, bnn = L.rv_off + L.cout - L.rm_off;
             if (pn > kHeadThreads || bnn > kHeadThreads || pn <= 0 || bnn <= 0 || h.n_seg + 2 > kHeadMaxSeg) return false;

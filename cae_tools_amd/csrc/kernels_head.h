@@ -9,8 +9,14 @@
 //                sums; ~0.1 MFLOP), then Linear 0..2 for its 16 batch rows, then its strip of Linear 3's columns.
 //                Workgroup (0,0) is the one that publishes the encoder's raw outputs, the saved / running BatchNorm
 //                statistics and the optimiser step bump; workgroups (*,0) publish the Linear activations.
-//   k_tail_bwd   Linear 2..0 input gradients for the whole batch (redundantly in every workgroup), the three weight
-//                gradients split over workgroups 1.., and in workgroup 0 the encoder's backward pass.
+//   k_tail_bwd   the backward pass of Linear 2..0: workgroups = (16-row groups of the batch) x (4 tasks); each walks the
+//                input-gradient chain for its rows as far as its task needs, then adds its rows' share of one weight
+//                gradient, or (task 0) writes the masked gradient for the encoder and its BatchNorm sums.
+//
+// Measured rules these follow (tools/head_phases.py prints per-phase wall-clock stamps of both kernels): every global read
+// is issued in one burst at kernel start; weights travel as coalesced 16-byte loads and reach the MFMA operand layout through
+// LDS (gathering them from global memory in that layout costs 16 cache lines per wave instruction); a phase on one CU is
+// bound by latency and instruction issue, not FLOPs, so work is spread over workgroups where no batch-wide sum forbids it.
 //
 // Same arithmetic as the kernels they replace (kernels_generic.h k_down / k_up / k_wgrad, kernels_gemm.h k_gemm16):
 // fp32 fmaf chains in the same order for the convolutions, v_mfma_f32_16x16x4_f32 for the Linear layers, fp64
@@ -25,7 +31,7 @@ namespace cae {
 constexpr int kHeadThreads = 1024;
 constexpr int kHeadWaves = kHeadThreads / 64;
 constexpr int kHeadMaxEnc = 4;
-constexpr int kHeadMaxC = 64;   // encoder channels the LDS tables are sized for
+constexpr int kHeadMaxC = 64;   // encoder channels (one thread per channel derives the BatchNorm constants)
 
 // How a stage's tiles are shared by the 16 waves (stage_split): 2^lg waves split the k-steps of one tile, `per` k-steps
 // each; 16 >> lg tiles are in flight per pass.
@@ -50,8 +56,6 @@ struct HeadConv {
     const float *w, *bias, *gamma, *beta;
     float *rmean, *rvar, *saved;
     float* y;           // raw conv output [B][cout][hout][wout] (kept for the backward pass)
-    float* g;           // tail: masked gradient wrt the BatchNorm output, same shape
-    double *w_acc, *gamma_acc, *beta_acc;   // tail: fp64 gradient slots
     double inv_count, unbias;   // 1 / (B * hout * wout) and count / (count - 1): BatchNorm statistics without fp64 divisions
     int o_y, o_c;       // LDS offsets (floats): output map; float4 BatchNorm constants
     int o_w, o_b, o_gamma, o_beta, o_rm, o_rv;   // LDS copies of the parameters (two segments: parameter block, running stats)
@@ -75,7 +79,6 @@ struct HeadArgs {
     float momentum, eps;
     const StepState* st;
     int tiles_per_wg;   // head: Linear-3 column tiles (16 wide) per workgroup
-    int n_wg;           // tail: workgroups in the launch
     int o_h[2], ld_h;   // LDS: two [rows][ld_h] activation / gradient panels
     int o_part, o_red, o_perm;
     int o_x;            // head: the gathered input batch [B][cin][hin][win]
