@@ -1030,7 +1030,12 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                     const int tiles_w = ((gw.M + 15) / 16) * ((gw.N + 15) / 16);
                     ProfScope _p(e, "linear_bwd_pair_mfma", i,
                                  f4((double)B * (3.0 * F.nin + 2.0 * F.nout) + (double)F.nin * F.nout) + 8.0 * F.nin * F.nout);
-                    hipLaunchKernelGGL(k_gemm16_pair, dim3(tiles_w + tiles_d), dim3(256), lds, s, gw, gd, tiles_w);
+                    // the input gradient's contraction runs over nout: long for the last decoder Linear (576 at cfg2): burst variant
+                    static const int burst_on = env_int("CAE_GEMM_BURST", 1);   // env: A/B measurements only
+                    const bool burst = burst_on && gd.epi != GE_BN_MASK && gd.sa_k == 1 && gd.sb_n == 1 && gd.K % 4 == 0 && gd.K >= 128 &&
+                                       (gd.K / 4 + 3) / 4 <= kBurstSteps && gd.sa_m % 4 == 0;
+                    if (burst && gemm16_burst_lds(gd.K) > lds) lds = gemm16_burst_lds(gd.K);
+                    hipLaunchKernelGGL(k_gemm16_pair, dim3(tiles_w + tiles_d), dim3(256), lds, s, gw, gd, tiles_w, burst ? 1 : 0);
                 }
                 if (i == 0)
                     if (int rc = sync_bn_table(e, a, P.bn_index)) return rc;

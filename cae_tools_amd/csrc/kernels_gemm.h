@@ -152,6 +152,95 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g, const int bx, dou
     }
 }
 
+// The same tile for a long contraction with A row-major (sa_k == 1), B[k][n] contiguous in n (sb_n == 1), K a multiple of
+// 4 and at most 4 * kBurstSteps k-steps: every operand read is issued in one burst at kernel start — this wave's B operands
+// into registers (4 cache lines per wave load), the tile's 16 A rows as coalesced 16-byte loads into LDS (fetched in the MFMA
+// lane layout they cost 16 lines per wave load), the ReLU-mask inputs of the epilogue — so the k loop runs out of LDS and
+// registers instead of paying a dependent memory round trip per batch of eight k-steps.  Epilogues: GE_STORE, GE_RELU_MASK.
+constexpr int kBurstSteps = 40;
+inline size_t gemm16_burst_lds(int K) { return (size_t)(4 * 256 + 16 * (K + 4)) * sizeof(float); }
+
+__device__ __forceinline__ void gemm16_burst_body(const GemmArgs& g, const int bx, double* lds_d) {
+    float* part = reinterpret_cast<float*>(lds_d);   // [4][256]
+    float* ap = part + 4 * 256;                      // [16][lda]
+    const int lda = g.K + 4;
+    const int tiles_n = (g.N + 15) >> 4;
+    const int tm = bx / tiles_n, tn = bx - tm * tiles_n;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int steps = g.K >> 2, per = (steps + 3) >> 2;
+    const int s0 = wv * per, s1 = min(steps, s0 + per);
+
+    const int bn = tn * 16 + r;
+    const float* bp = g.B + (long long)min(bn, g.N - 1) * g.sb_n;
+    // ---- one burst: B operands, epilogue inputs, the tile's A rows; nothing is consumed before all of it is in flight ----
+    float b[kBurstSteps];
+#pragma unroll
+    for (int u = 0; u < kBurstSteps; u++) b[u] = bp[(long long)min((s0 + u) * 4 + q, g.K - 1) * g.sb_k];
+    const int cn = tn * 16 + r;
+    float hmask[4] = {1.f, 1.f, 1.f, 1.f};
+    if (g.epi == GE_RELU_MASK) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            hmask[j] = g.H[(long long)min(tm * 16 + q * 4 + j, g.M - 1) * g.sc_m + (long long)min(cn, g.N - 1) * g.sc_n];
+    }
+    const float bias = (g.epi == GE_STORE && g.bias) ? g.bias[min(cn, g.N - 1)] : 0.f;
+    // float4s of the A panel per thread: 16 rows * (K / 4) / 256 threads <= 16 * (4 * kBurstSteps) / 256
+    static_assert(16 * (4 * kBurstSteps) / 256 == 10, "A panel registers");
+    const int k4 = g.K >> 2, n4 = 16 * k4;
+    const float inv_k4 = 1.0f / (float)k4;
+    f32x4 av[10];
+#pragma unroll
+    for (int u = 0; u < 10; u++) {
+        const int i = min(tid + u * 256, n4 - 1);
+        const int row = div_small(i, inv_k4);
+        av[u] = *reinterpret_cast<const f32x4*>(g.A + (long long)min(tm * 16 + row, g.M - 1) * g.sa_m + 4 * (i - row * k4));
+    }
+    // The loads above are unconditional (clamped addresses) and must stay so: left to itself the compiler moves each one
+    // under the predicate of its consumer and waits for it there — forty dependent round trips instead of one burst.
+#pragma unroll
+    for (int u = 0; u < kBurstSteps; u++) asm volatile("" : "+v"(b[u]));
+    asm volatile("" : "+v"(hmask[0]), "+v"(hmask[1]), "+v"(hmask[2]), "+v"(hmask[3]));
+#pragma unroll
+    for (int u = 0; u < 10; u++) asm volatile("" : "+v"(av[u]));
+#pragma unroll
+    for (int u = 0; u < kBurstSteps; u++) b[u] = ((s0 + u) < s1 && bn < g.N) ? b[u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 10; u++) {
+        const int i = tid + u * 256;
+        if (i < n4) {
+            const int row = div_small(i, inv_k4);
+            *reinterpret_cast<f32x4*>(ap + row * lda + 4 * (i - row * k4)) = tm * 16 + row < g.M ? av[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* arow = ap + r * lda + q;
+#pragma unroll
+    for (int u = 0; u < kBurstSteps; u++) {
+        const int k4 = min(s0 + u, steps - 1);   // past this wave's range b[u] is zero; keep the read inside the panel
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * k4], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) part[wv * 256 + j * 64 + lane] = acc[j];
+    __syncthreads();
+    if (wv != 0 || cn >= g.N) return;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int cm = tm * 16 + q * 4 + j;
+        if (cm >= g.M) continue;
+        float v = part[j * 64 + lane] + part[256 + j * 64 + lane] + part[512 + j * 64 + lane] + part[768 + j * 64 + lane];
+        const long long off = (long long)cm * g.sc_m + (long long)cn * g.sc_n;
+        if (g.epi == GE_STORE) {
+            v += bias;
+            if (g.relu) v = fmaxf(v, 0.f);
+        } else {
+            v = hmask[j] > 0.f ? v : 0.f;
+        }
+        g.C[off] = v;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_gemm16(GemmArgs g) {
     extern __shared__ double lds_d[];
     gemm16_body(g, blockIdx.x, lds_d);
@@ -159,9 +248,10 @@ __global__ void __launch_bounds__(256) k_gemm16(GemmArgs g) {
 
 // two independent GEMMs in one launch (a Linear layer's weight gradient beside its input gradient):
 // workgroups [0, na) run `a`, the rest run `b`
-__global__ void __launch_bounds__(256) k_gemm16_pair(GemmArgs a, GemmArgs b, int na) {
+__global__ void __launch_bounds__(256) k_gemm16_pair(GemmArgs a, GemmArgs b, int na, int b_burst) {
     extern __shared__ double lds_d[];
     if ((int)blockIdx.x < na) gemm16_body(a, blockIdx.x, lds_d);
+    else if (b_burst) gemm16_burst_body(b, blockIdx.x - na, lds_d);
     else gemm16_body(b, blockIdx.x - na, lds_d);
 }
 
