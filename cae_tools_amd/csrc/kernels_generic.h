@@ -383,6 +383,53 @@ __device__ __forceinline__ void up_body(const ConvGeom& g, const Src& small, con
         // thread instead of one per (channel, tap)
         const int y0 = Y / g.s, x0 = X / g.s;
         const int ky0 = Y - y0 * g.s, kx0 = X - x0 * g.s;
+        if (g.kh <= 2 * g.s && g.kw <= 2 * g.s) {
+            // At most 2 x 2 taps per output (3x3 or 4x4 kernels at stride 2).  The general loop below issues one load, waits,
+            // multiplies, per (channel, tap): ~16 dependent memory round trips per thread.  Here four channels' taps, their
+            // raw outputs (BatchNorm backward) and weights are fetched together from clamped addresses, then consumed in
+            // the same (channel, ky, kx) order.
+            int yy[2], xx[2], kyy[2], kxx[2];
+            bool vy[2], vx[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int ky = ky0 + t * g.s, y = y0 - t, kx = kx0 + t * g.s, x = x0 - t;
+                vy[t] = ky < g.kh && y >= 0 && y < g.Hs;
+                vx[t] = kx < g.kw && x >= 0 && x < g.Ws;
+                yy[t] = min(max(y, 0), g.Hs - 1);
+                xx[t] = min(max(x, 0), g.Ws - 1);
+                kyy[t] = min(ky, g.kh - 1);
+                kxx[t] = min(kx, g.kw - 1);
+            }
+            const int khw = g.kh * g.kw;
+            for (int c0 = 0; c0 < g.Cs; c0 += 4) {
+                float gv[4][4], qv[4][4], wv[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int cs = min(c0 + c, g.Cs - 1);
+                    const float* wp = w + (size_t)(cs * g.Cl + cl) * khw;
+                    const size_t base = (sb * g.Cs + cs) * (size_t)g.Hs * g.Ws;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const size_t off = base + (size_t)yy[t >> 1] * g.Ws + xx[t & 1];
+                        gv[c][t] = small.p[off];
+                        qv[c][t] = bns.mode == BN_BWD ? small.q[off] : 0.f;
+                        wv[c][t] = wp[kyy[t >> 1] * g.kw + kxx[t & 1]];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) asm volatile("" : "+v"(gv[c][t]), "+v"(qv[c][t]), "+v"(wv[c][t]));
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (c0 + c >= g.Cs) break;
+                    const float4 k = bns.mode ? cs4[c0 + c] : make_float4(0, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        if (vy[t >> 1] && vx[t & 1]) acc = fmaf(bn_apply(bns.mode, k, gv[c][t], qv[c][t]), wv[c][t], acc);
+                }
+            }
+        } else
         for (int cs = 0; cs < g.Cs; cs++) {
             const float* wp = w + (size_t)(cs * g.Cl + cl) * g.kh * g.kw;
             const size_t base = (sb * g.Cs + cs) * (size_t)g.Hs * g.Ws;
