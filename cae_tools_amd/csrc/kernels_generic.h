@@ -705,10 +705,16 @@ __device__ __forceinline__ float consume_grad(const StepTail& tl, const ShardSeg
     for (int s = 0; s < ss.nseg; s++) {
         const long long d = i - ss.seg[s].param_off;
         if (d >= 0 && d < ss.seg[s].count) {
+            // all eight shard reads in flight before the first clearing store (a load/store per shard in turn is eight
+            // dependent round trips for the threads that own sharded parameters: the tail of this kernel)
+            double* p = tl.shard_rw + ss.seg[s].sh_off + d;
+            double v[kStatShards];
+#pragma unroll
+            for (int sh = 0; sh < kStatShards; sh++) v[sh] = p[(size_t)sh * ss.n];
+#pragma unroll
             for (int sh = 0; sh < kStatShards; sh++) {
-                double* p = tl.shard_rw + (size_t)sh * ss.n + ss.seg[s].sh_off + d;
-                g += *p;
-                *p = 0.0;
+                g += v[sh];
+                p[(size_t)sh * ss.n] = 0.0;
             }
         }
     }
