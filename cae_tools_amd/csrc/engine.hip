@@ -767,6 +767,10 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             f.KH = L.kh; f.KW = L.kw; f.QH = (L.hout + 1) / 2; f.QW = (L.wout + 1) / 2;
             f.in = small.p; f.bn_in = bns; f.w = e->params + L.w_off; f.bias = e->params + L.b_off;
             f.out = ep.out; f.stats = a.train ? ep.stats : nullptr;
+            {
+                static const int dbg = env_int("CAE_HEAD_DBG", 0);   // tools/head_phases.py ig: stamps of the LAST such layer
+                f.dbg = dbg && a.train ? reinterpret_cast<long long*>(e->ws + e->off_scan) : nullptr;
+            }
             const int mtiles = (B * f.QH * f.QW + 15) / 16;
             f.ksplit = L.cin >= 48 ? 4 : (L.cin >= 24 ? 2 : 1);
             // at most ~1024 workgroups over the 4 parities: every workgroup ends with up to 32 fp64 atomics
@@ -1617,6 +1621,10 @@ int64_t cae_debug_read(cae_engine* e, const char* what, int index, void* host_ou
         if (index < 0 || index > 3) return fail(CAE_ERR_ARG, "fc index out of range");
         src = e->ws + e->fc[index].grad_off;
         n = mb * e->fc[index].nout;
+    } else if (w == "scan") {   // the loader's scratch: where tools/head_phases.py's decoder-kernel stamps land
+        src = e->ws + e->off_scan;
+        n = 1024 * 3;
+        esz = 8;
     } else if (w == "grad_acc") {
         src = e->gradacc();
         n = e->n_param;

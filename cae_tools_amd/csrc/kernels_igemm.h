@@ -31,17 +31,21 @@ struct IgFwd {
     const float* bias;
     float* out;
     double* stats;  // [shards][Cout][4] or nullptr (eval)
+    long long* dbg; // diagnostics (tools/head_phases.py ig): 8 wall-clock stamps per workgroup of parity 0, or nullptr
 };
 
 // grid (ceil(Mtiles / (4*tiles_per_wave)), 4 parities, ceil(Cout/16)), block 256
 __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
+#define IG_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) a.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
     extern __shared__ double lds_d[];
+    IG_STAMP(0);
     float* lstat = reinterpret_cast<float*>(lds_d);  // [16 channels][2]
     float* part = lstat + 32;                        // [4 waves][256] split-K partial tiles
     float4* cin4 = reinterpret_cast<float4*>(part + 1024);
     bn_consts(a.bn_in, cin4, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
     if (threadIdx.x < 32) lstat[threadIdx.x] = 0.f;
     __syncthreads();
+    IG_STAMP(1);
 
     const int py = blockIdx.y >> 1, px = blockIdx.y & 1;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -50,6 +54,8 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
     const int QQ = a.QH * a.QW;
     const int M = a.B * QQ;
     const int HW = a.H * a.W;
+    const bool fastdiv = M + 16 < kDivSmallMaxN && QQ < kDivSmallMaxD;
+    const float inv_qq = 1.0f / (float)QQ, inv_qw = 1.0f / (float)a.QW;
     const int co = blockIdx.z * 16 + r;              // B column / C column of this lane
     const int ky = py + 2 * j, kx = px + 2 * i;
     const bool b_ok = co < a.Cout && ky < a.KH && kx < a.KW;
@@ -68,8 +74,15 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
         // A row of this lane: quad m -> (b, qm, qn)
         const int m = tile * 16 + r;
         bool a_ok = tile_ok && m < M;
-        const int b = m / QQ, rem = m - b * QQ;
-        const int qm = rem / a.QW, qn = rem - qm * a.QW;
+        int b, qm;   // 3-instruction fp32 products instead of ~40-instruction integer divisions (ten of them per tile)
+        if (fastdiv) {
+            b = div_small(m, inv_qq);
+            qm = div_small(m - b * QQ, inv_qw);
+        } else {
+            b = m / QQ;
+            qm = (m - b * QQ) / a.QW;
+        }
+        const int rem = m - b * QQ, qn = rem - qm * a.QW;
         const int iy = qm - j, ix = qn - i;
         a_ok = a_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const float* ap = a.in + (size_t)b * a.Cin * HW + (size_t)iy * a.W + ix;
@@ -91,6 +104,7 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
 #pragma unroll
             for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
         }
+        IG_STAMP(2);
         if (KS > 1) {   // combine the K slices of this M-tile in the slice-0 wave
             __syncthreads();
 #pragma unroll
@@ -108,8 +122,15 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
             for (int jj = 0; jj < 4; jj++) {
                 const int cm = tile * 16 + q * 4 + jj;
                 if (cm >= M) continue;
-                const int cb = cm / QQ, crem = cm - cb * QQ;
-                const int cqm = crem / a.QW, cqn = crem - cqm * a.QW;
+                int cb, cqm;
+                if (fastdiv) {
+                    cb = div_small(cm, inv_qq);
+                    cqm = div_small(cm - cb * QQ, inv_qw);
+                } else {
+                    cb = cm / QQ;
+                    cqm = (cm - cb * QQ) / a.QW;
+                }
+                const int crem = cm - cb * QQ, cqn = crem - cqm * a.QW;
                 const int oy = 2 * cqm + py, ox = 2 * cqn + px;
                 if (oy >= a.OH || ox >= a.OW) continue;
                 const float v = acc[jj] + bias;
@@ -119,6 +140,7 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
             }
         }
     }
+    IG_STAMP(3);
     if (a.stats) {
         // lanes r, r+16, r+32, r+48 hold the same channel: fold, then LDS, then one fp64 atomic per value
         s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
@@ -135,7 +157,8 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
                 atomicAdd(&a.stats[((size_t)shard * a.Cout + c) * 4 + (threadIdx.x & 1)], (double)lstat[threadIdx.x]);
             }
         }
-    }
+        IG_STAMP(4);
+}
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -76,7 +76,36 @@ def tail():
     print(f"whole grid: {(st[:, :, 7].max() - st[:, :, 0].min()) / 100.0:.2f} us")
 
 
+def ig():
+    """k_ig_fwd_s2 of the last gather-MFMA decoder layer (the stamps of later launches overwrite earlier ones): parity-0
+    workgroups' stamps"""
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    spec = create_model_spec(input_size=(16, 16), input_channels=1, output_size=(256, 256), output_channels=1)
+    eng = HipEngine(spec, 128, 32, B, device="cuda:0", graph=False)
+    torch.manual_seed(0)
+    eng.params.normal_(0, 0.05)
+    eng.set_dataset(0, torch.rand((B, 1, 16, 16), device="cuda:0"), torch.rand((B, 1, 256, 256), device="cuda:0"))
+    rows = []
+    for it in range(20):
+        eng.forward_backward(0, None, 0, B, B)
+        eng.sync()
+        raw = eng.debug_read("scan", 0, count=3072, dtype=np.float64)
+        rows.append(raw.view(np.int64)[: 256 * 8].reshape(256, 8).astype(np.float64))
+    st = np.stack(rows[5:])[-1][:, :5]          # one launch (medians across launches would mix different dispatch orders)
+    ok = (st[:, 0] > 0) & (np.diff(st, axis=1) >= 0).all(axis=1) & (st[:, 4] - st[:, 0] < 1e5)
+    print(f"{int(ok.sum())} of {len(ok)} parity-0 workgroups with a complete stamp set")
+    st = st[ok]
+    d = np.diff(st, axis=1) / 100.0
+    for i, name in enumerate(["BatchNorm constants", "operand loads + MFMA", "combine + stores", "statistics + atomics"]):
+        print(f"{name:24s} median {np.median(d[:, i]):6.2f} us   max {d[:, i].max():6.2f}")
+    print(f"workgroup lifetime: median {np.median(st[:, 4] - st[:, 0]) / 100:.2f} us; first start .. last end {(st[:, 4].max() - st[:, 0].min()) / 100:.2f} us; "
+          f"start spread {(st[:, 0].max() - st[:, 0].min()) / 100:.2f} us")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "ig":
+        ig()
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "tail":
         tail()
         sys.exit(0)
