@@ -59,7 +59,6 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
     const int co = blockIdx.z * 16 + r;              // B column / C column of this lane
     const int ky = py + 2 * j, kx = px + 2 * i;
     const bool b_ok = co < a.Cout && ky < a.KH && kx < a.KW;
-    const float* bp = a.w + ((size_t)co * a.KH + ky) * a.KW + kx;
     const size_t b_step = (size_t)a.Cout * a.KH * a.KW;
     const float bias = co < a.Cout ? a.bias[co] : 0.f;
     float s1 = 0.f, s2 = 0.f;
@@ -85,21 +84,32 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
         const int rem = m - b * QQ, qn = rem - qm * a.QW;
         const int iy = qm - j, ix = qn - i;
         a_ok = a_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        const float* ap = a.in + (size_t)b * a.Cin * HW + (size_t)iy * a.W + ix;
+        // Lean operand fetch: this phase is bound by instruction issue (16 waves per CU run ~700 instructions each around
+        // 16 MFMAs: tools/head_phases.py ig), so a load is `wave-uniform channel base + loop-invariant 32-bit lane offset`
+        // (one instruction, no 64-bit lane arithmetic), issued unconditionally from an in-range address, and invalid lanes /
+        // channels are zeroed by one select after the BatchNorm transform.
+        const unsigned a_off = a_ok ? (unsigned)((b * a.Cin) * HW + iy * a.W + ix) : 0u;
+        const unsigned b_off = b_ok ? (unsigned)((co * a.KH + ky) * a.KW + kx) : 0u;
 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int c0 = cbeg; c0 < cend; c0 += 8) {
             float av[8], bv[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
+                const int cc = min(c0 + u, a.Cin - 1);   // wave-uniform
+                av[u] = (a.in + (size_t)cc * HW)[a_off];
+                bv[u] = (a.w + (size_t)cc * b_step)[b_off];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
                 const int ci = c0 + u;
                 const bool c_ok = ci < cend;
-                av[u] = (a_ok && c_ok) ? ap[(size_t)ci * HW] : 0.f;
-                bv[u] = (b_ok && c_ok) ? bp[(size_t)ci * b_step] : 0.f;
-                if (a.bn_in.mode != BN_NONE && a_ok && c_ok) {
-                    const float4 k = cin4[ci];
+                if (a.bn_in.mode != BN_NONE) {
+                    const float4 k = cin4[min(ci, a.Cin - 1)];
                     av[u] = fmaxf(0.f, fmaf(av[u] - k.x, k.y, k.z));
                 }
+                av[u] = (a_ok && c_ok) ? av[u] : 0.f;
+                bv[u] = (b_ok && c_ok) ? bv[u] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
