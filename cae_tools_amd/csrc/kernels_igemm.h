@@ -344,9 +344,8 @@ __device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, co
     const int n = tn * 16 + r;                       // B column of this lane: (co, ky, kx)
     const bool a_ok = ci < a.Cin, b_ok = n < N;
     const int co = b_ok ? n / khw : 0;
-    const int t = n - co * khw;
+    const int t = b_ok ? n - co * khw : 0;
     const int ky = t / a.KW, kx = t - ky * a.KW;
-    const size_t nbase = ((size_t)co * a.OH + ky) * a.OW + kx;
     const float4 ka = (a.bn_in.mode != BN_NONE && a_ok) ? cin4[ci] : make_float4(0, 0, 0, 0);
     const float4 kb = (a.bn_out.mode == BN_BWD && b_ok) ? cout4[co] : make_float4(0, 0, 0, 0);
 
@@ -356,17 +355,21 @@ __device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, co
     const int per = (s_end - s_begin + 3) >> 2;
     const int s0 = s_begin + wv * per, s1 = min(s_end, s0 + per);
 
+    // Lean operand fetch (see k_ig_fwd_s2): 32-bit offsets from the tensor bases (one load instruction each, no 64-bit lane
+    // arithmetic), always from an in-range address (clamped position / row / column), zeroed by one select afterwards.
     const bool fastdiv = K < kDivSmallMaxN && HW < kDivSmallMaxD;
     const float inv_hw = 1.0f / (float)HW, inv_w = 1.0f / (float)a.W;
+    const unsigned a_lane = (unsigned)(min(ci, a.Cin - 1) * HW);                          // + (b * Cin) * HW + pos
+    const unsigned b_lane = (unsigned)((co * a.OH + ky) * a.OW + kx);                     // + b * Cout*OH*OW + S*y*OW + S*x
+    const unsigned img_a = (unsigned)(a.Cin * HW), img_b = (unsigned)(a.Cout * a.OH * a.OW);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int st = s0; st < s1; st += 8) {
-        float av[8], bv[8];
+        float av[8], bv[8], yv[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int k = (st + u) * 4 + q;
-            const bool k_ok = (st + u) < s1 && k < K;
+            const int k = min((st + u) * 4 + q, K - 1);
             int b, y;
-            if (fastdiv) {   // two integer divisions per operand element were most of this loop's instructions
+            if (fastdiv) {
                 b = div_small(k, inv_hw);
                 y = div_small(k - b * HW, inv_w);
             } else {
@@ -374,18 +377,20 @@ __device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, co
                 y = (k - b * HW) / a.W;
             }
             const int pos = k - b * HW, x = pos - y * a.W;
-            float va = 0.f, vb = 0.f;
-            if (a_ok && k_ok) {
-                va = a.ain[((size_t)b * a.Cin + ci) * HW + pos];
-                if (a.bn_in.mode != BN_NONE) va = fmaxf(0.f, fmaf(va - ka.x, ka.y, ka.z));
-            }
-            if (b_ok && k_ok) {
-                const size_t off = (size_t)b * a.Cout * a.OH * a.OW + (size_t)(a.S * y) * a.OW + a.S * x + nbase;
-                vb = a.g[off];
-                if (a.bn_out.mode == BN_BWD) vb = kb.y * vb - kb.z - (a.yout[off] - kb.x) * kb.w;
-            }
-            av[u] = va;
-            bv[u] = vb;
+            const unsigned oa = (unsigned)b * img_a + (unsigned)pos + a_lane;
+            const unsigned ob = (unsigned)b * img_b + (unsigned)((a.S * y) * a.OW + a.S * x) + b_lane;
+            av[u] = a.ain[oa];
+            bv[u] = a.g[ob];
+            yv[u] = a.bn_out.mode == BN_BWD ? a.yout[ob] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool k_ok = (st + u) < s1 && (st + u) * 4 + q < K;
+            float va = av[u], vb = bv[u];
+            if (a.bn_in.mode != BN_NONE) va = fmaxf(0.f, fmaf(va - ka.x, ka.y, ka.z));
+            if (a.bn_out.mode == BN_BWD) vb = kb.y * vb - kb.z - (yv[u] - kb.x) * kb.w;
+            av[u] = (a_ok && k_ok) ? va : 0.f;
+            bv[u] = (b_ok && k_ok) ? vb : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
