@@ -908,7 +908,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             const int per_block = (4 / fd.ksplit) * fd.tiles_per_wave;
             const int d_gx = (mtiles + per_block - 1) / per_block, d_gy = (L.cin + 15) / 16;
             const size_t lds_d = (32 + 1024) * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4) +
-                                 (size_t)L.cout * L.kh * L.kw * sizeof(int);
+                                 (size_t)L.cout * L.kh * L.kw * 2 * sizeof(int);
             const size_t lds_w = 1024 * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4);
             ProfScope _p(e, "ig_convt_bwd_pair", l,
                          f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));

@@ -193,13 +193,13 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
     float* part = lstat + 32;                                     // [4][256] split-K partial tiles
     float4* cout4 = reinterpret_cast<float4*>(part + 1024);       // [Cout]
     float4* cprev4 = cout4 + a.Cout;                              // [Cin]
-    int* koff = reinterpret_cast<int*>(cprev4 + a.Cin);           // [K] offset of tap k inside one image of gy
+    int2* koff = reinterpret_cast<int2*>(cprev4 + a.Cin);         // [K] {offset of tap k inside one image of gy, its channel}
     bn_consts(a.bn_out, cout4, false);
     bn_consts(a.bn_prev, cprev4, false);
     for (int k = threadIdx.x; k < K; k += 256) {
         const int co = k / (a.KH * a.KW), t = k - co * (a.KH * a.KW);
         const int ky = t / a.KW, kx = t - ky * a.KW;
-        koff[k] = (co * a.OH + ky) * a.OW + kx;
+        koff[k] = make_int2((co * a.OH + ky) * a.OW + kx, co);
     }
     if (threadIdx.x < 32) lstat[threadIdx.x] = 0.f;
     __syncthreads();
@@ -210,10 +210,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
     const int M = a.B * HW;
     const int ci = by * 16 + r;
     const bool b_ok = ci < a.Cin;
-    const float* bp = a.w + (size_t)ci * K;
-    const int khw = a.KH * a.KW;
-    const bool fastdiv = K < kDivSmallMaxN && khw < kDivSmallMaxD;
-    const float inv_khw = 1.0f / (float)khw;
+    const unsigned w_lane = (unsigned)(min(ci, a.Cin - 1) * K);
     float d1 = 0.f, d2 = 0.f;
 
     const int KS = a.ksplit;
@@ -225,28 +222,36 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
         const bool tile_ok = tile * 16 < M;
         const int m = tile * 16 + r;
         const bool a_ok = tile_ok && m < M;
-        const int b = m / HW, rem = m - b * HW;
+        const int mc = a_ok ? m : 0;
+        const int b = mc / HW, rem = mc - b * HW;
         const int y = rem / a.W, x = rem - y * a.W;
-        const size_t abase = (size_t)b * a.Cout * a.OH * a.OW + (size_t)(a.S * y) * a.OW + a.S * x;
+        // lean operand fetch (see k_ig_fwd_s2): 32-bit offsets, always in range (clamped row and k), one select afterwards
+        const unsigned abase = (unsigned)(b * a.Cout * a.OH * a.OW + (a.S * y) * a.OW + a.S * x);
 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int k0 = kbeg; k0 < kend; k0 += 48) {
-            float av[12], bv[12];
+            float av[12], bv[12], yv[12];
+            int ch[12];
 #pragma unroll
             for (int u = 0; u < 12; u++) {
-                const int k = k0 + 4 * u + q;
-                const bool k_ok = k < kend;
-                float v = 0.f;
-                if (a_ok && k_ok) {
-                    const size_t off = abase + koff[k];
-                    v = a.g[off];
-                    if (a.bn_out.mode == BN_BWD) {
-                        const float4 c4 = cout4[fastdiv ? div_small(k, inv_khw) : k / khw];
-                        v = c4.y * v - c4.z - (a.yout[off] - c4.x) * c4.w;
-                    }
+                const int kc = min(k0 + 4 * u + q, kend - 1);
+                const int2 kk = koff[kc];
+                const unsigned off = abase + (unsigned)kk.x;
+                ch[u] = kk.y;
+                av[u] = a.g[off];
+                yv[u] = a.bn_out.mode == BN_BWD ? a.yout[off] : 0.f;
+                bv[u] = a.w[w_lane + (unsigned)kc];
+            }
+#pragma unroll
+            for (int u = 0; u < 12; u++) {
+                const bool k_ok = k0 + 4 * u + q < kend;
+                float v = av[u];
+                if (a.bn_out.mode == BN_BWD) {
+                    const float4 c4 = cout4[ch[u]];
+                    v = c4.y * v - c4.z - (yv[u] - c4.x) * c4.w;
                 }
-                av[u] = v;
-                bv[u] = (b_ok && k_ok) ? bp[k] : 0.f;
+                av[u] = (a_ok && k_ok) ? v : 0.f;
+                bv[u] = (b_ok && k_ok) ? bv[u] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 12; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
