@@ -769,7 +769,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             f.out = ep.out; f.stats = a.train ? ep.stats : nullptr;
             {
                 static const int dbg = env_int("CAE_HEAD_DBG", 0);   // tools/head_phases.py ig: stamps of the LAST such layer
-                f.dbg = dbg && a.train ? reinterpret_cast<long long*>(e->ws + e->off_scan) : nullptr;
+                f.dbg = dbg == 1 && a.train ? reinterpret_cast<long long*>(e->ws + e->off_scan) : nullptr;
             }
             const int mtiles = (B * f.QH * f.QW + 15) / 16;
             f.ksplit = L.cin >= 48 ? 4 : (L.cin >= 24 ? 2 : 1);
@@ -912,6 +912,10 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             const size_t lds_w = 1024 * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4);
             ProfScope _p(e, "ig_convt_bwd_pair", l,
                          f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));
+            {
+                static const int dbg = env_int("CAE_HEAD_DBG", 0);   // tools/head_phases.py igb: stamps of decoder layer 2's pair
+                fw.dbg = fd.dbg = dbg == 2 && l == 2 ? reinterpret_cast<long long*>(e->ws + e->off_scan) : nullptr;
+            }
             // XCD-aware order (kernels_igemm.h): d_group input-gradient blocks cover the positions of one weight-gradient chunk
             int d_group = (per * 4) / (per_block * 16);
             if (d_group < 1) d_group = 1;

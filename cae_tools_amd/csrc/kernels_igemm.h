@@ -184,10 +184,13 @@ struct IgDgrad {
     const float* yprev;    // raw output of the producer (mask) or nullptr: plain store
     BnDesc bn_prev;        // BN_SAVED of the producer or BN_NONE
     double* stats_prev;    // [shards][Cin][4] slots 2,3
+    long long* dbg;        // diagnostics: 4 stamps per workgroup at dbg[(512 + bx) * 4 ..], or nullptr
 };
 
 // grid (ceil(Mtiles / (4*tiles_per_wave)), ceil(Cin/16)), block 256; LDS: see host
 __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, const int by, double* lds_d) {
+#define IGD_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && by == 0 && bx < 256) a.dbg[(512 + bx) * 4 + (i)] = wall_clock64(); } while (0)
+    IGD_STAMP(0);
     const int K = a.Cout * a.KH * a.KW;
     float* lstat = reinterpret_cast<float*>(lds_d);               // [16][2]
     float* part = lstat + 32;                                     // [4][256] split-K partial tiles
@@ -203,6 +206,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
     }
     if (threadIdx.x < 32) lstat[threadIdx.x] = 0.f;
     __syncthreads();
+    IGD_STAMP(1);
 
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
@@ -211,7 +215,6 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
     const int ci = by * 16 + r;
     const bool b_ok = ci < a.Cin;
     const unsigned w_lane = (unsigned)(min(ci, a.Cin - 1) * K);
-    float d1 = 0.f, d2 = 0.f;
 
     const int KS = a.ksplit;
     const int mslot = wv / KS, kslot = wv - mslot * KS;
@@ -256,6 +259,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
 #pragma unroll
             for (int u = 0; u < 12; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
         }
+        IGD_STAMP(2);
         if (KS > 1) {
             __syncthreads();
 #pragma unroll
@@ -267,32 +271,47 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
                     for (int jj = 0; jj < 4; jj++) acc[jj] += part[(wv + o) * 256 + jj * 64 + lane];
             }
         }
-        if (b_ok && kslot == 0 && tile_ok) {
+        if (kslot == 0 && tile_ok) {
+            // The MFMA leaves C as (row = position, column = channel) with the channel along the lanes, but the tensors are
+            // channel-major: stored from that layout every store / yprev load touches 16 lines.  Transposed through the wave's
+            // own LDS tile, a lane owns one position and four channels: 16 consecutive positions per instruction and channel.
+            float* tl = part + wv * 256;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) tl[(q * 4 + jj) * 16 + r] = acc[jj];
+            const int cm = tile * 16 + r;               // this lane's position; channels by * 16 + q * 4 + jj
+            const bool m_ok = cm < M;
+            const int cmc = m_ok ? cm : 0;
+            const int cb = cmc / HW, crem = cmc - cb * HW;
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
-                const int cm = tile * 16 + q * 4 + jj;
-                if (cm >= M) continue;
-                const int cb = cm / HW, crem = cm - cb * HW;
-                const size_t off = ((size_t)cb * a.Cin + ci) * HW + crem;
-                float v = acc[jj];
+                const int cc = by * 16 + q * 4 + jj;
+                const bool ok = m_ok && cc < a.Cin;
+                const size_t off = ((size_t)cb * a.Cin + min(cc, a.Cin - 1)) * HW + crem;
+                float v = tl[r * 16 + q * 4 + jj];
+                float e1 = 0.f, e2 = 0.f;
                 if (a.bn_prev.mode != BN_NONE) {
-                    const float4 c4 = cprev4[ci];
+                    const float4 c4 = cprev4[min(cc, a.Cin - 1)];
                     const float d = a.yprev[off] - c4.x;
                     v = fmaf(d, c4.y, c4.z) > 0.f ? v : 0.f;
-                    d1 += v;
-                    d2 = fmaf(v, d * c4.w, d2);
+                    e1 = ok ? v : 0.f;
+                    e2 = e1 * (d * c4.w);
                 }
-                a.gin[off] = v;
+                if (ok) a.gin[off] = v;
+                if (a.stats_prev) {
+                    // channel cc's sums over the 16 positions of this row of lanes (DPP row reduction: lane 15 of the row)
+                    e1 += dpp_f<0xB1>(e1); e2 += dpp_f<0xB1>(e2);
+                    e1 += dpp_f<0x4E>(e1); e2 += dpp_f<0x4E>(e2);
+                    e1 += dpp_f<0x141>(e1); e2 += dpp_f<0x141>(e2);
+                    e1 += dpp_f<0x140>(e1); e2 += dpp_f<0x140>(e2);
+                    if (r == 15 && cc < a.Cin) {
+                        atomicAdd(&lstat[2 * (q * 4 + jj)], e1);
+                        atomicAdd(&lstat[2 * (q * 4 + jj) + 1], e2);
+                    }
+                }
             }
         }
     }
     if (a.stats_prev) {
-        d1 += __shfl_xor(d1, 16, 64); d2 += __shfl_xor(d2, 16, 64);
-        d1 += __shfl_xor(d1, 32, 64); d2 += __shfl_xor(d2, 32, 64);
-        if (q == 0 && b_ok) {
-            atomicAdd(&lstat[2 * r], d1);
-            atomicAdd(&lstat[2 * r + 1], d2);
-        }
         __syncthreads();
         if (threadIdx.x < 32) {
             const int c = by * 16 + (threadIdx.x >> 1);
@@ -302,6 +321,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
             }
         }
     }
+    IGD_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -315,10 +335,14 @@ struct IgWgrad {
     BnDesc bn_out;         // BN_BWD or BN_NONE
     double* wacc;          // (Cin, Cout*KH*KW) fp64 accumulator
     BnGradOut bg;
+    long long* dbg;        // diagnostics: 4 stamps per workgroup at dbg[(by * tiles + bx) * 4 ..] for the first 512, or nullptr
 };
 
 // grid (Mtiles*Ntiles, K chunks), block 256: the 4 waves split the chunk, LDS combine, fp64 atomics
 __device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, const int by, double* lds_d) {
+#define IGW_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && wslot < 512) a.dbg[wslot * 4 + (i)] = wall_clock64(); } while (0)
+    const int wslot = by * (((a.Cin + 15) >> 4) * ((a.Cout * a.KH * a.KW + 15) >> 4)) + bx;
+    IGW_STAMP(0);
     float* part = reinterpret_cast<float*>(lds_d);            // [4][256]
     float4* cin4 = reinterpret_cast<float4*>(part + 1024);    // [Cin]
     float4* cout4 = cin4 + a.Cin;                             // [Cout]
@@ -336,6 +360,7 @@ __device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, co
         }
     }
     __syncthreads();
+    IGW_STAMP(1);
 
     const int khw = a.KH * a.KW;
     const int N = a.Cout * khw;
@@ -400,12 +425,16 @@ __device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, co
 #pragma unroll
         for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
     }
+    IGW_STAMP(2);
 #pragma unroll
     for (int j = 0; j < 4; j++) part[wv * 256 + j * 64 + lane] = acc[j];
     __syncthreads();
     if (wv != 0) return;
     const int cn = tn * 16 + r;
-    if (cn >= N) return;
+    if (cn >= N) {
+        IGW_STAMP(3);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int cm = tm * 16 + q * 4 + j;
@@ -413,6 +442,7 @@ __device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, co
         const float v = part[j * 64 + lane] + part[256 + j * 64 + lane] + part[512 + j * 64 + lane] + part[768 + j * 64 + lane];
         atomicAdd(&a.wacc[(size_t)cm * N + cn], (double)v);
     }
+    IGW_STAMP(3);
 }
 
 __global__ void __launch_bounds__(256) k_ig_dgrad(IgDgrad a) {

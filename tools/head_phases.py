@@ -102,7 +102,36 @@ def ig():
           f"start spread {(st[:, 0].max() - st[:, 0].min()) / 100:.2f} us")
 
 
+def igb():
+    """k_ig_bwd_pair of decoder layer 2 (CAE_HEAD_DBG=2): stamps of the first 512 weight-gradient and 256 input-gradient
+    workgroups"""
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    spec = create_model_spec(input_size=(16, 16), input_channels=1, output_size=(256, 256), output_channels=1)
+    eng = HipEngine(spec, 128, 32, B, device="cuda:0", graph=False)
+    torch.manual_seed(0)
+    eng.params.normal_(0, 0.05)
+    eng.set_dataset(0, torch.rand((B, 1, 16, 16), device="cuda:0"), torch.rand((B, 1, 256, 256), device="cuda:0"))
+    for it in range(12):
+        eng.forward_backward(0, None, 0, B, B)
+        eng.sync()
+    raw = eng.debug_read("scan", 0, count=3072, dtype=np.float64).view(np.int64).astype(np.float64)
+    t0 = None
+    for (name, lo, n) in (("weight gradient", 0, 512), ("input gradient", 512, 256)):
+        st = raw[lo * 4:(lo + n) * 4].reshape(n, 4)
+        ok = (st[:, 0] > 0) & (np.diff(st, axis=1) >= 0).all(axis=1) & (st[:, 3] - st[:, 0] < 1e5)
+        st = st[ok]
+        t0 = st[:, 0].min() if t0 is None else min(t0, st[:, 0].min())
+        d = np.diff(st, axis=1) / 100.0
+        print(f"{name}: {len(st)} workgroups; constants {np.median(d[:, 0]):.2f}  operand fetch + MFMA {np.median(d[:, 1]):.2f}  "
+              f"epilogue {np.median(d[:, 2]):.2f} us; lifetime {np.median(st[:, 3] - st[:, 0]) / 100:.2f} us; "
+              f"starts {(st[:, 0].min() - t0) / 100:.2f}..{(st[:, 0].max() - t0) / 100:.2f}, last end {(st[:, 3].max() - t0) / 100:.2f} us")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "igb":
+        os.environ["CAE_HEAD_DBG"] = "2"
+        igb()
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "ig":
         ig()
         sys.exit(0)
