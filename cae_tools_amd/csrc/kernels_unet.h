@@ -80,6 +80,35 @@ __device__ __forceinline__ float drop_factor(const Drop& d, unsigned long long i
     return r >= d.thr ? d.scale : 0.f;
 }
 
+
+// (b, c, y, x) of flat index idx in a (B, C, H, W) tensor.  Four 64-bit div/mod pairs cost ~400 instructions per output
+// element; three fp32 products do the same while idx < 2^22 * ... each quotient is exact (see plane_loop); otherwise 32- or
+// 64-bit integer division.
+struct Nchw {
+    int b, c, y, x;
+};
+__device__ __forceinline__ Nchw nchw_of(long long idx, int C, int H, int W) {
+    Nchw r;
+    if (idx < (1LL << 31)) {
+        const unsigned i = (unsigned)idx, w = (unsigned)W, h = (unsigned)H, c = (unsigned)C;
+        const unsigned q1 = i / w;
+        r.x = (int)(i - q1 * w);
+        const unsigned q2 = q1 / h;
+        r.y = (int)(q1 - q2 * h);
+        const unsigned q3 = q2 / c;
+        r.c = (int)(q2 - q3 * c);
+        r.b = (int)q3;
+    } else {
+        r.x = (int)(idx % W);
+        long long t = idx / W;
+        r.y = (int)(t % H);
+        t /= H;
+        r.c = (int)(t % C);
+        r.b = (int)(t / C);
+    }
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // generic convolutions (fallback for any geometry)
 // ---------------------------------------------------------------------------------------------
@@ -87,12 +116,8 @@ __global__ void __launch_bounds__(256) k_down(Geom g, const float* __restrict__ 
                                               const float* __restrict__ bias, float* __restrict__ S) {
     const long long total = (long long)g.B * g.Cs * g.Hs * g.Ws;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int x = (int)(idx % g.Ws);
-        long long r = idx / g.Ws;
-        const int y = (int)(r % g.Hs);
-        r /= g.Hs;
-        const int cs = (int)(r % g.Cs);
-        const int b = (int)(r / g.Cs);
+        const Nchw o = nchw_of(idx, g.Cs, g.Hs, g.Ws);
+        const int x = o.x, y = o.y, cs = o.c, b = o.b;
         float acc = bias ? bias[cs] : 0.f;
         const float* wp = w + (size_t)cs * g.Cl * g.kh * g.kw;
         for (int cl = 0; cl < g.Cl; cl++) {
@@ -115,22 +140,16 @@ __global__ void __launch_bounds__(256) k_up(Geom g, const float* __restrict__ S,
                                             const float* __restrict__ bias, float* __restrict__ L) {
     const long long total = (long long)g.B * g.Cl * g.Hl * g.Wl;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int X = (int)(idx % g.Wl);
-        long long r = idx / g.Wl;
-        const int Y = (int)(r % g.Hl);
-        r /= g.Hl;
-        const int cl = (int)(r % g.Cl);
-        const int b = (int)(r / g.Cl);
+        const Nchw o = nchw_of(idx, g.Cl, g.Hl, g.Wl);
+        const int X = o.x, Y = o.y, cl = o.c, b = o.b;
         float acc = bias ? bias[cl] : 0.f;
-        for (int ky = 0; ky < g.kh; ky++) {
-            const int ty = Y + g.p - ky;
-            if (ty < 0 || ty % g.s) continue;
-            const int y = ty / g.s;
+        // only the taps of this output's parity: ky = (Y + p) mod s, + s, ... reading row y = (Y + p) / s, - 1, ... (one
+        // division per dimension per output instead of a modulo and a division per tap)
+        const int y0 = (Y + g.p) / g.s, x0 = (X + g.p) / g.s;
+        const int ky0 = Y + g.p - y0 * g.s, kx0 = X + g.p - x0 * g.s;
+        for (int ky = ky0, y = y0; ky < g.kh && y >= 0; ky += g.s, y--) {
             if (y >= g.Hs) continue;
-            for (int kx = 0; kx < g.kw; kx++) {
-                const int tx = X + g.p - kx;
-                if (tx < 0 || tx % g.s) continue;
-                const int x = tx / g.s;
+            for (int kx = kx0, x = x0; kx < g.kw && x >= 0; kx += g.s, x--) {
                 if (x >= g.Ws) continue;
                 const float* sp = S + (size_t)b * g.Cs * g.Hs * g.Ws + (size_t)y * g.Ws + x;
                 const float* wp = w + ((size_t)cl * g.kh + ky) * g.kw + kx;
@@ -156,10 +175,19 @@ __global__ void __launch_bounds__(256) k_wgrad(Geom g, const float* __restrict__
     const int per = g.Hs * g.Ws;
     const long long total = (long long)g.B * per;
     double sum = 0.0;
+    const bool fast = total < (1LL << 22) && per < 8000;   // exact fp32-product quotients (see plane_loop)
+    const float inv_per = 1.0f / (float)per, inv_w = 1.0f / (float)g.Ws;
     for (long long e = (long long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long long)gridDim.y * 256) {
-        const int b = (int)(e / per);
+        int b, y;
+        if (fast) {
+            b = (int)(((float)(int)e + 0.5f) * inv_per);
+            y = (int)(((float)((int)e - b * per) + 0.5f) * inv_w);
+        } else {
+            b = (int)(e / per);
+            y = (int)(e - (long long)b * per) / g.Ws;
+        }
         const int r = (int)(e - (long long)b * per);
-        const int y = r / g.Ws, x = r - y * g.Ws;
+        const int x = r - y * g.Ws;
         const int Y = y * g.s + ky - g.p, X = x * g.s + kx - g.p;
         if (Y < 0 || Y >= g.Hl || X < 0 || X >= g.Wl) continue;
         sum += (double)(S[((size_t)b * g.Cs + cs) * per + r] * L[(((size_t)b * g.Cl + cl) * g.Hl + Y) * g.Wl + X]);
