@@ -488,12 +488,28 @@ __global__ void __launch_bounds__(256) k_pool(const float* __restrict__ u, int H
     double s = 0;
     float mx = -INFINITY;
     int am = 0x7fffffff;
-    for (int i = threadIdx.x; i < HW; i += 256) {
-        const float v = p[i];
-        s += (double)v;
-        if (v > mx) {
-            mx = v;
-            am = i;
+    if ((HW & 3) == 0) {   // 16-byte loads; elements visited in increasing index per thread, so the first maximum is kept
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+            const float4 t4 = p4[i];
+            const float v[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                s += (double)v[j];
+                if (v[j] > mx) {
+                    mx = v[j];
+                    am = 4 * i + j;
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const float v = p[i];
+            s += (double)v;
+            if (v > mx) {
+                mx = v;
+                am = i;
+            }
         }
     }
     smax[threadIdx.x] = mx;
@@ -597,7 +613,16 @@ __global__ void __launch_bounds__(256) k_att_da(const float* __restrict__ dcat, 
     const float* gp = dcat + ((size_t)b * 2 * C + c) * HW;
     const float* up = u + (size_t)blockIdx.x * HW;
     double s = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) s += (double)(gp[i] * up[i]);
+    if ((HW & 3) == 0) {   // 16-byte loads: both planes start on a multiple of HW floats
+        const float4* g4 = reinterpret_cast<const float4*>(gp);
+        const float4* u4 = reinterpret_cast<const float4*>(up);
+        for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+            const float4 a = g4[i], b = u4[i];
+            s += (double)(a.x * b.x) + (double)(a.y * b.y) + (double)(a.z * b.z) + (double)(a.w * b.w);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 256) s += (double)(gp[i] * up[i]);
+    }
     const double t = block_sum(s, red);
     if (threadIdx.x == 0) da[blockIdx.x] = (float)t;
 }
@@ -747,6 +772,17 @@ __global__ void __launch_bounds__(256) k_lin_wgrad(int B, int nin, int nout, con
 // dst[b][:] = src[perm ? perm[start+b] : start+b][:]
 __global__ void __launch_bounds__(256) k_gather(const float* __restrict__ src, const int* __restrict__ perm, long long start,
                                                 int B, long long E, float* __restrict__ dst) {
+    if ((E & 3) == 0) {   // rows are whole float4s: 16-byte copies, one 64-bit division per four elements
+        const long long E4 = E >> 2, total4 = (long long)B * E4;
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total4; o += (long long)gridDim.x * 256) {
+            const long long b = o / E4, i = o - b * E4;
+            const long long s = perm ? (long long)perm[start + b] : start + b;
+            d4[o] = s4[s * E4 + i];
+        }
+        return;
+    }
     const long long total = (long long)B * E;
     for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
         const long long b = o / E, i = o - b * E;
