@@ -188,6 +188,8 @@ struct IgDgrad {
 };
 
 // grid (ceil(Mtiles / (4*tiles_per_wave)), ceil(Cin/16)), block 256; LDS: see host
+constexpr int kIgdSteps = 9;
+
 __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, const int by, double* lds_d) {
 #define IGD_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && by == 0 && bx < 256) a.dbg[(512 + bx) * 4 + (i)] = wall_clock64(); } while (0)
     IGD_STAMP(0);
@@ -218,7 +220,9 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
 
     const int KS = a.ksplit;
     const int mslot = wv / KS, kslot = wv - mslot * KS;
-    const int kper = (((K + 3) / 4 + KS - 1) / KS + 11) / 12 * 48;  // k per slice, multiple of 48 (12 MFMA steps)
+    // k per slice, a multiple of one batch of kIgdSteps MFMA k-steps: the benchmark layers' slices (Cout * 9 / ksplit = 36, 36
+    // and 72 k) are whole batches of 9, so no batch carries padding steps (12-deep batches were a quarter padding there)
+    const int kper = (((K + 3) / 4 + KS - 1) / KS + kIgdSteps - 1) / kIgdSteps * (4 * kIgdSteps);
     const int kbeg = kslot * kper, kend = min(K, kbeg + kper);
     for (int tt = 0; tt < a.tiles_per_wave; tt++) {
         const int tile = (bx * (4 / KS) + mslot) * a.tiles_per_wave + tt;
@@ -232,11 +236,11 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
         const unsigned abase = (unsigned)(b * a.Cout * a.OH * a.OW + (a.S * y) * a.OW + a.S * x);
 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = kbeg; k0 < kend; k0 += 48) {
-            float av[12], bv[12], yv[12];
-            int ch[12];
+        for (int k0 = kbeg; k0 < kend; k0 += 4 * kIgdSteps) {
+            float av[kIgdSteps], bv[kIgdSteps], yv[kIgdSteps];
+            int ch[kIgdSteps];
 #pragma unroll
-            for (int u = 0; u < 12; u++) {
+            for (int u = 0; u < kIgdSteps; u++) {
                 const int kc = min(k0 + 4 * u + q, kend - 1);
                 const int2 kk = koff[kc];
                 const unsigned off = abase + (unsigned)kk.x;
@@ -246,7 +250,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
                 bv[u] = a.w[w_lane + (unsigned)kc];
             }
 #pragma unroll
-            for (int u = 0; u < 12; u++) {
+            for (int u = 0; u < kIgdSteps; u++) {
                 const bool k_ok = k0 + 4 * u + q < kend;
                 float v = av[u];
                 if (a.bn_out.mode == BN_BWD) {
@@ -257,7 +261,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
                 bv[u] = (b_ok && k_ok) ? bv[u] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 12; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < kIgdSteps; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
         }
         IGD_STAMP(2);
         if (KS > 1) {
