@@ -189,6 +189,13 @@ struct IgDgrad {
 
 // grid (ceil(Mtiles / (4*tiles_per_wave)), ceil(Cin/16)), block 256; LDS: see host
 constexpr int kIgdSteps = 9;
+// 4-byte aligned 12- and 16-byte loads (global memory takes them unaligned)
+struct __attribute__((packed, aligned(4))) F3 {
+    float x, y, z;
+};
+struct __attribute__((packed, aligned(4))) F4 {
+    float x, y, z, w;
+};
 
 __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, const int by, double* lds_d) {
 #define IGD_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && by == 0 && bx < 256) a.dbg[(512 + bx) * 4 + (i)] = wall_clock64(); } while (0)
@@ -217,6 +224,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
     const int ci = by * 16 + r;
     const bool b_ok = ci < a.Cin;
     const unsigned w_lane = (unsigned)(min(ci, a.Cin - 1) * K);
+    const bool k33 = a.KH == 3 && a.KW == 3 && kIgdSteps == 9;
 
     const int KS = a.ksplit;
     const int mslot = wv / KS, kslot = wv - mslot * KS;
@@ -238,6 +246,42 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int k0 = kbeg; k0 < kend; k0 += 4 * kIgdSteps) {
             float av[kIgdSteps], bv[kIgdSteps], yv[kIgdSteps];
+            if (k33) {
+                // 3x3 kernels: a batch is 36 k = four output channels' 3x3 taps.  The vector-memory pipe, not bytes or FLOPs,
+                // bounds this phase (each 64-lane load instruction costs it ~16 cycles whatever it hits; with every load
+                // removed the phase is 2.1 us instead of 6.6): so lane group q takes ALL nine taps of channel k0/9 + q —
+                // three 12-byte row loads each of g and y and three loads of its nine contiguous weights instead of 27
+                // dword loads — and slot (u, q) of the MFMA holds k = k0 + 9q + u on both operands.
+                const int co = k0 / 9 + q;
+                const bool c_ok = co * 9 < kend;
+                const int coc = min(co, a.Cout - 1);
+                const unsigned base = abase + (unsigned)(coc * a.OH * a.OW);
+                const float* wp = a.w + w_lane + coc * 9;
+                F3 g3[3], y3[3];
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++) {
+                    g3[ky] = *reinterpret_cast<const F3*>(a.g + base + ky * a.OW);
+                    if (a.bn_out.mode == BN_BWD) y3[ky] = *reinterpret_cast<const F3*>(a.yout + base + ky * a.OW);
+                }
+                const F4 w0 = *reinterpret_cast<const F4*>(wp), w1 = *reinterpret_cast<const F4*>(wp + 4);
+                const float w8 = wp[8];
+                const float wv9[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w8};
+                const float4 c4 = a.bn_out.mode == BN_BWD ? cout4[coc] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 9; u++) {
+                    const F3 gr = g3[u / 3], yr = y3[u / 3];
+                    float v = u % 3 == 0 ? gr.x : (u % 3 == 1 ? gr.y : gr.z);
+                    if (a.bn_out.mode == BN_BWD) {
+                        const float yy = u % 3 == 0 ? yr.x : (u % 3 == 1 ? yr.y : yr.z);
+                        v = c4.y * v - c4.z - (yy - c4.x) * c4.w;
+                    }
+                    av[u] = (a_ok && c_ok) ? v : 0.f;
+                    bv[u] = (b_ok && c_ok) ? wv9[u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 9; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+                continue;
+            }
             int ch[kIgdSteps];
 #pragma unroll
             for (int u = 0; u < kIgdSteps; u++) {
