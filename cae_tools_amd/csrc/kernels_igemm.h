@@ -20,6 +20,17 @@
 namespace cae {
 
 
+// 4-byte aligned 8-, 12- and 16-byte loads (global memory takes them unaligned)
+struct __attribute__((packed, aligned(4))) F2 {
+    float x, y;
+};
+struct __attribute__((packed, aligned(4))) F3 {
+    float x, y, z;
+};
+struct __attribute__((packed, aligned(4))) F4 {
+    float x, y, z, w;
+};
+
 // ---------------------------------------------------------------------------------------------
 struct IgFwd {
     int B, Cin, H, W, Cout, OH, OW, KH, KW, QH, QW;
@@ -92,7 +103,51 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
         const unsigned b_off = b_ok ? (unsigned)((co * a.KH + ky) * a.KW + kx) : 0u;
 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int c0 = cbeg; c0 < cend; c0 += 8) {
+        // Paired-tap variant (the vector-memory instruction count bounds this phase, see ig_dgrad_body): lane group q takes
+        // row tap jp = q & 1 and BOTH column taps of every second channel (parity q >> 1): one 8-byte load of two adjacent
+        // inputs and one 12-byte load of the weight row per channel instead of two dword loads each; slot u = 2t + i of the
+        // MFMA holds k = (channel c0 + 2t + (q >> 1), row tap jp, column tap i) on both operands.
+        const bool paired = a.W >= 2;
+        const int jp = q & 1, hp = q >> 1;
+        const int iyp = qm - jp;
+        const bool rowp_ok = tile_ok && m < M && iyp >= 0 && iyp < a.H;
+        const int cst = min(max(qn - 1, 0), a.W - 2);                 // first column of the loaded pair
+        const int d0 = qn - cst, d1 = qn - 1 - cst;                   // where column taps i = 0 / 1 sit in the pair (0, 1: valid)
+        const bool v0 = rowp_ok && qn < a.W && (unsigned)d0 < 2u, v1 = rowp_ok && qn >= 1 && (unsigned)d1 < 2u;
+        const unsigned ap_off = rowp_ok ? (unsigned)((b * a.Cin) * HW + iyp * a.W + cst) : 0u;
+        const int kyp = py + 2 * jp;
+        const bool wrow_ok = co < a.Cout && kyp < a.KH;
+        const bool w0_ok = wrow_ok && px < a.KW, w1_ok = wrow_ok && px + 2 < a.KW;
+        const unsigned bp_off = wrow_ok ? (unsigned)((co * a.KH + kyp) * a.KW + px) : 0u;
+        for (int c0 = cbeg; paired && c0 < cend; c0 += 8) {
+            float av[8], bv[8];
+            F2 x2[4];
+            F3 w3[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int cc = min(c0 + 2 * t + hp, a.Cin - 1);
+                x2[t] = *reinterpret_cast<const F2*>(a.in + (size_t)cc * HW + ap_off);
+                w3[t] = *reinterpret_cast<const F3*>(a.w + (size_t)cc * b_step + bp_off);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int ci = c0 + 2 * t + hp;
+                const bool c_ok = ci < cend;
+                float e0 = d0 == 0 ? x2[t].x : x2[t].y, e1 = d1 == 0 ? x2[t].x : x2[t].y;
+                if (a.bn_in.mode != BN_NONE) {
+                    const float4 k = cin4[min(ci, a.Cin - 1)];
+                    e0 = fmaxf(0.f, fmaf(e0 - k.x, k.y, k.z));
+                    e1 = fmaxf(0.f, fmaf(e1 - k.x, k.y, k.z));
+                }
+                av[2 * t] = (v0 && c_ok) ? e0 : 0.f;
+                av[2 * t + 1] = (v1 && c_ok) ? e1 : 0.f;
+                bv[2 * t] = (w0_ok && c_ok) ? w3[t].x : 0.f;
+                bv[2 * t + 1] = (w1_ok && c_ok) ? w3[t].z : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        for (int c0 = cbeg; !paired && c0 < cend; c0 += 8) {
             float av[8], bv[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -189,13 +244,6 @@ struct IgDgrad {
 
 // grid (ceil(Mtiles / (4*tiles_per_wave)), ceil(Cin/16)), block 256; LDS: see host
 constexpr int kIgdSteps = 9;
-// 4-byte aligned 12- and 16-byte loads (global memory takes them unaligned)
-struct __attribute__((packed, aligned(4))) F3 {
-    float x, y, z;
-};
-struct __attribute__((packed, aligned(4))) F4 {
-    float x, y, z, w;
-};
 
 __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, const int by, double* lds_d) {
 #define IGD_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && by == 0 && bx < 256) a.dbg[(512 + bx) * 4 + (i)] = wall_clock64(); } while (0)
