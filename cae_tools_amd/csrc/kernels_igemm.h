@@ -291,6 +291,16 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
         // lean operand fetch (see k_ig_fwd_s2): 32-bit offsets, always in range (clamped row and k), one select afterwards
         const unsigned abase = (unsigned)(b * a.Cout * a.OH * a.OW + (a.S * y) * a.OW + a.S * x);
 
+        // epilogue inputs of this lane (position m, channels by * 16 + 4q + jj), requested before the k loop so that their
+        // latency hides behind it
+        unsigned eoff[4];
+        float yp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            eoff[jj] = (unsigned)((b * a.Cin + min(by * 16 + q * 4 + jj, a.Cin - 1)) * HW + rem);
+            if (a.bn_prev.mode != BN_NONE && kslot == 0) yp[jj] = a.yprev[eoff[jj]];
+        }
+
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int k0 = kbeg; k0 < kend; k0 += 4 * kIgdSteps) {
             float av[kIgdSteps], bv[kIgdSteps], yv[kIgdSteps];
@@ -374,20 +384,17 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
             float* tl = part + wv * 256;
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) tl[(q * 4 + jj) * 16 + r] = acc[jj];
-            const int cm = tile * 16 + r;               // this lane's position; channels by * 16 + q * 4 + jj
-            const bool m_ok = cm < M;
-            const int cmc = m_ok ? cm : 0;
-            const int cb = cmc / HW, crem = cmc - cb * HW;
+            const bool m_ok = a_ok;                     // this lane's position is m; channels by * 16 + q * 4 + jj
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
                 const int cc = by * 16 + q * 4 + jj;
                 const bool ok = m_ok && cc < a.Cin;
-                const size_t off = ((size_t)cb * a.Cin + min(cc, a.Cin - 1)) * HW + crem;
+                const unsigned off = eoff[jj];
                 float v = tl[r * 16 + q * 4 + jj];
                 float e1 = 0.f, e2 = 0.f;
                 if (a.bn_prev.mode != BN_NONE) {
                     const float4 c4 = cprev4[min(cc, a.Cin - 1)];
-                    const float d = a.yprev[off] - c4.x;
+                    const float d = yp[jj] - c4.x;
                     v = fmaf(d, c4.y, c4.z) > 0.f ? v : 0.f;
                     e1 = ok ? v : 0.f;
                     e2 = e1 * (d * c4.w);
