@@ -23,6 +23,30 @@
 
 namespace cae {
 
+// One patch row (KW = 3 or 4 contiguous floats) as ONE 12- / 16-byte load: 4-byte alignment is all global memory needs, and the
+// count of vector-memory instructions — not their bytes — is what the backward kernels' patch fetch costs (each 64-lane load
+// occupies the CU's address pipe for ~16 cycles; a thread of the 8->4 layer's backward fetched 72 dwords per pixel).
+struct __attribute__((packed, aligned(4))) S2Row3 {
+    float v[3];
+};
+struct __attribute__((packed, aligned(4))) S2Row4 {
+    float v[4];
+};
+template <int KW>
+__device__ __forceinline__ void s2_load_row(const float* __restrict__ p, float (&dst)[KW]) {
+    if constexpr (KW == 3) {
+        const S2Row3 r = *reinterpret_cast<const S2Row3*>(p);
+        dst[0] = r.v[0]; dst[1] = r.v[1]; dst[2] = r.v[2];
+    } else if constexpr (KW == 4) {
+        const S2Row4 r = *reinterpret_cast<const S2Row4*>(p);
+        dst[0] = r.v[0]; dst[1] = r.v[1]; dst[2] = r.v[2]; dst[3] = r.v[3];
+    } else {
+#pragma unroll
+        for (int kx = 0; kx < KW; kx++) dst[kx] = p[kx];
+    }
+}
+
+
 struct S2Fwd {
     int B, H, W, OH, OW;     // input map H x W, output map OH x OW (per channel)
     int tiles_x, tiles_y;    // quad tiles per image
@@ -666,16 +690,16 @@ __global__ void __launch_bounds__(256) k_s2_bwd2(S2Bwd a) {
             const float* yp = a.yout ? a.yout + (size_t)(b * COUT + co) * OHW + pbase : nullptr;
             float p[KH][KW];
 #pragma unroll
-            for (int ky = 0; ky < KH; ky++)
-#pragma unroll
-                for (int kx = 0; kx < KW; kx++) p[ky][kx] = gp[ky * a.OW + kx];
+            for (int ky = 0; ky < KH; ky++) s2_load_row<KW>(gp + ky * a.OW, p[ky]);
             if (a.bn_out.mode == BN_BWD) {
                 const float4 k = cout4[co];
+                float yr[KH][KW];
+#pragma unroll
+                for (int ky = 0; ky < KH; ky++) s2_load_row<KW>(yp + ky * a.OW, yr[ky]);
 #pragma unroll
                 for (int ky = 0; ky < KH; ky++)
 #pragma unroll
-                    for (int kx = 0; kx < KW; kx++)
-                        p[ky][kx] = k.y * p[ky][kx] - k.z - (yp[ky * a.OW + kx] - k.x) * k.w;
+                    for (int kx = 0; kx < KW; kx++) p[ky][kx] = k.y * p[ky][kx] - k.z - (yr[ky][kx] - k.x) * k.w;
             }
 #pragma unroll
             for (int ci = 0; ci < CIN; ci++) {
@@ -805,18 +829,14 @@ __global__ void __launch_bounds__(256) k_s2_bwd_split(S2Bwd a) {
         for (int co = 0; co < COUT; co++) {
             const float* gp = a.g + (size_t)(b * COUT + co) * OHW + pbase;
 #pragma unroll
-            for (int ky = 0; ky < KH; ky++)
-#pragma unroll
-                for (int kx = 0; kx < KW; kx++) pg[co][ky][kx] = gp[ky * a.OW + kx];
+            for (int ky = 0; ky < KH; ky++) s2_load_row<KW>(gp + ky * a.OW, pg[co][ky]);
         }
         if (a.bn_out.mode == BN_BWD) {
 #pragma unroll
             for (int co = 0; co < COUT; co++) {
                 const float* yp = a.yout + (size_t)(b * COUT + co) * OHW + pbase;
 #pragma unroll
-                for (int ky = 0; ky < KH; ky++)
-#pragma unroll
-                    for (int kx = 0; kx < KW; kx++) py[co][ky][kx] = yp[ky * a.OW + kx];
+                for (int ky = 0; ky < KH; ky++) s2_load_row<KW>(yp + ky * a.OW, py[co][ky]);
             }
         }
 #pragma unroll
