@@ -904,7 +904,8 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             const int mtiles = (B * L.hin * L.win + 15) / 16;
             const int ksteps = (L.cout * L.kh * L.kw + 3) / 4;
             fd.ksplit = ksteps > 24 ? 4 : (ksteps > 12 ? 2 : 1);   // <= 12 k-steps (one load batch) per wave where possible
-            fd.tiles_per_wave = mtiles >= 8192 ? 2 : 1;
+            static const int tpw_env = env_int("CAE_IG_DGRAD_TPW", 0);   // env: tuning only
+            fd.tiles_per_wave = tpw_env > 0 ? tpw_env : (mtiles >= 8192 ? 2 : 1);
             const int per_block = (4 / fd.ksplit) * fd.tiles_per_wave;
             const int d_gx = (mtiles + per_block - 1) / per_block, d_gy = (L.cin + 15) / 16;
             const size_t lds_d = (32 + 1024) * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4) +
