@@ -256,7 +256,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
     int2* koff = reinterpret_cast<int2*>(cprev4 + a.Cin);         // [K] {offset of tap k inside one image of gy, its channel}
     bn_consts(a.bn_out, cout4, false);
     bn_consts(a.bn_prev, cprev4, false);
-    for (int k = threadIdx.x; k < K; k += 256) {
+    for (int k = threadIdx.x; k < K && !(a.KH == 3 && a.KW == 3); k += 256) {   // the 3x3 path below needs no tap table
         const int co = k / (a.KH * a.KW), t = k - co * (a.KH * a.KW);
         const int ky = t / a.KW, kx = t - ky * a.KW;
         koff[k] = make_int2((co * a.OH + ky) * a.OW + kx, co);
