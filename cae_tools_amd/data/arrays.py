@@ -154,8 +154,9 @@ def _is_hdf5(path):
         return f.read(4) == b"\x89HDF"
 
 
-def open_dataset(path):
-    """One NetCDF file -> Dataset (arrays are read-only views of the file mapping)."""
+def open_dataset(path, mask_and_scale=True):
+    """One NetCDF file -> Dataset (arrays are read-only views of the file mapping).  mask_and_scale: CF decoding of
+    _FillValue / missing_value / scale_factor / add_offset as xarray applies by default (decode_cf below)."""
     if _is_hdf5(path):
         try:
             import xarray as xr
@@ -169,8 +170,56 @@ def open_dataset(path):
     for name, var in f.variables.items():
         # big-endian views of the file mapping (kept alive by the arrays): nothing is read until it is used, and
         # DSDataset uploads contiguous float32 slabs as raw bytes and swaps them on the GPU
-        out[name] = DataArray(var.data, dims=var.dimensions, attrs=dict(var.attributes))
+        (data, attrs) = decode_cf(var.data, dict(var.attributes)) if mask_and_scale else (var.data, dict(var.attributes))
+        out[name] = DataArray(data, dims=var.dimensions, attrs=attrs)
     return out
+
+
+_CF_KEYS = ("_FillValue", "missing_value", "scale_factor", "add_offset")
+
+
+def decode_cf(data, attrs):
+    """What xarray's default `mask_and_scale=True` does to a variable on open (the reference reads every file through
+    xr.open_mfdataset, cli/train_cae.py:58-59): values equal to `_FillValue` / `missing_value` become NaN, then
+    `decoded = raw * scale_factor + add_offset`; the four attributes leave `attrs` (xarray moves them to .encoding).
+    So a filled pixel reaches DSDataset as NaN and trips its 'contains N NaN values' ValueError (ds_dataset.py:43-46)
+    instead of silently becoming the normalisation minimum, and packed integer variables are trained on in their
+    physical units.  Returns (array, attrs).  A float variable whose fill value never occurs keeps its file-backed
+    big-endian view (the raw-bytes upload path); everything else is decoded into a native-endian array.
+    Result dtype as xarray chooses it: floats keep theirs; integers of <= 16 bits give float32 unless an add_offset
+    is present (float64, unless both scale_factor and add_offset are float32); wider integers give float64."""
+    if data.dtype.kind not in "iuf" or not any(k in attrs for k in _CF_KEYS):
+        return data, attrs
+    fills = []
+    for key in ("_FillValue", "missing_value"):
+        if key in attrs:
+            fills.extend(np.atleast_1d(np.asarray(attrs[key])).tolist())
+    scale, offset = attrs.get("scale_factor"), attrs.get("add_offset")
+    rest = {k: v for k, v in attrs.items() if k not in _CF_KEYS}
+    native = data.dtype.newbyteorder("=")
+    if native.kind == "f":
+        out_dtype = native
+    elif native.itemsize <= 2 and (offset is None or (np.asarray(scale).dtype == np.float32
+                                                      and np.asarray(offset).dtype == np.float32)):
+        out_dtype = np.dtype(np.float32)
+    else:
+        out_dtype = np.dtype(np.float64)
+    mask = None
+    for fv in fills:
+        if isinstance(fv, float) and fv != fv:
+            continue   # a NaN fill value: those pixels already read as NaN
+        hit = data == np.asarray(fv).astype(native)
+        mask = hit if mask is None else (mask | hit)
+    if scale is None and offset is None and native.kind == "f" and (mask is None or not mask.any()):
+        return data, rest
+    out = np.array(data, dtype=out_dtype)
+    if mask is not None and mask.any():
+        out[mask] = np.nan
+    if scale is not None:
+        out *= np.asarray(scale).astype(out_dtype).reshape(-1)[0]
+    if offset is not None:
+        out += np.asarray(offset).astype(out_dtype).reshape(-1)[0]
+    return out, rest
 
 
 def from_xarray(xds):
@@ -181,7 +230,7 @@ def from_xarray(xds):
     return out
 
 
-def open_mfdataset(paths, concat_dim="box", combine="nested", **_ignored):
+def open_mfdataset(paths, concat_dim="box", combine="nested", mask_and_scale=True, **_ignored):
     """Nested concatenation of several files along a NEW or existing dimension, the way the CLIs
     call xr.open_mfdataset(paths, concat_dim="box", combine="nested") (cli/train_cae.py:58-59):
     variables that carry `concat_dim` are concatenated along it; if no variable has that dimension
@@ -189,7 +238,7 @@ def open_mfdataset(paths, concat_dim="box", combine="nested", **_ignored):
     single file xarray then leaves the data unchanged, which is what this does too."""
     if isinstance(paths, (str, os.PathLike)):
         paths = [paths]
-    parts = [open_dataset(p) for p in paths]
+    parts = [open_dataset(p, mask_and_scale=mask_and_scale) for p in paths]
     if len(parts) == 1:
         return parts[0]
     out = Dataset(attrs=parts[0].attrs)

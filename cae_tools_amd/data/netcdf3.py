@@ -260,16 +260,28 @@ def _enc_attributes(attrs):
     return struct.pack(">II", NC_ATTRIBUTE, len(items)) + b"".join(items)
 
 
-def _storable(arr):
+def _storable(arr, name="?"):
+    """the array in a type NetCDF-3 can hold, never changing a value: bool -> byte, float16 -> float, uint8 -> short,
+    uint16 -> int, and uint32 / 64-bit integers -> int when every value fits, double when that is exact, else an error
+    (the classic format has no unsigned and no 64-bit integer types)."""
     arr = np.asarray(arr)
     if arr.dtype == bool:
         return arr.astype(np.int8)
     if arr.dtype.kind == "f" and arr.dtype.itemsize == 2:
         return arr.astype(np.float32)
-    if arr.dtype.kind in "iu" and arr.dtype.itemsize == 8:
-        return arr.astype(np.int32)     # NetCDF-3 has no 64-bit integers
-    if arr.dtype.kind == "u" and arr.dtype.itemsize in (2, 4):
-        return arr.astype(np.int32)     # ... and no unsigned 16/32-bit ones
+    if arr.dtype.kind == "u" and arr.dtype.itemsize == 1:
+        return arr.astype(np.int16)     # NC_BYTE is signed: 200 would read back as -56
+    if arr.dtype.kind == "u" and arr.dtype.itemsize == 2:
+        return arr.astype(np.int32)
+    if arr.dtype.kind in "iu" and arr.dtype.itemsize >= 4 and arr.dtype != np.dtype(np.int32):
+        if arr.size == 0:
+            return arr.astype(np.int32)
+        (lo, hi) = (int(arr.min()), int(arr.max()))
+        if -2 ** 31 <= lo and hi < 2 ** 31:
+            return arr.astype(np.int32)
+        if -2 ** 53 <= lo and hi <= 2 ** 53:
+            return arr.astype(np.float64)   # exact for |v| <= 2^53
+        raise NetCDFError(f"variable {name}: {arr.dtype} values in [{lo}, {hi}] fit neither NC_INT nor NC_DOUBLE exactly")
     return arr
 
 
@@ -279,9 +291,12 @@ def write(path, dimensions, variables, attributes=None, version=2):
     if version not in (1, 2):
         raise NetCDFError("version must be 1 (classic) or 2 (64-bit offset)")
     dim_names = list(dimensions)
+    for (d, n) in dimensions.items():
+        if int(n) <= 0:   # length 0 in the header MEANS "the record dimension": a zero-length fixed one cannot be written
+            raise NetCDFError(f"dimension {d}: length {n} (NetCDF-3 reads a zero-length dimension as the unlimited one)")
     prepared = []
     for (name, (dims, arr, attrs)) in variables.items():
-        arr = _storable(arr)
+        arr = _storable(arr, name)
         code = ("S1" if arr.dtype.kind == "S" else arr.dtype.kind + str(arr.dtype.itemsize))
         if code not in _TYPE_OF:
             raise NetCDFError(f"variable {name}: dtype {arr.dtype} cannot be stored in NetCDF-3")

@@ -151,6 +151,100 @@ def test_errors(tmp_path):
         netcdf3.write(str(tmp_path / "bad.nc"), {"x": 2}, {"v": (("x",), np.zeros(2, dtype=np.complex64), {})})
 
 
+def _cf_file(tmp_path):
+    """one file with the four CF-packed shapes xarray decodes on open (the reference opens everything through
+    xr.open_mfdataset, whose default is mask_and_scale=True: cli/train_cae.py:58-59)"""
+    rng = np.random.default_rng(8)
+    f = rng.random((3, 1, 4, 4)).astype(np.float32)
+    f[1, 0, 2, 3] = -9999.0
+    clean = rng.random((3, 1, 4, 4)).astype(np.float32)
+    packed = rng.integers(-1000, 1000, (3, 1, 4, 4)).astype(np.int16)
+    packed[0, 0, 0, 0] = -32768
+    counts = rng.integers(0, 50, (3, 1, 4, 4)).astype(np.int32)
+    counts[2, 0, 1, 1] = -1
+    dims = {"n": 3, "c": 1, "y": 4, "x": 4}
+    d = ("n", "c", "y", "x")
+    path = str(tmp_path / "cf.nc")
+    netcdf3.write(path, dims, {
+        "filled": (d, f, {"_FillValue": np.float32(-9999.0), "units": "K"}),
+        "clean": (d, clean, {"_FillValue": np.float32(-9999.0), "missing_value": np.float32(-8888.0)}),
+        "packed": (d, packed, {"_FillValue": np.int16(-32768), "scale_factor": np.float64(0.01), "add_offset": np.float64(273.15)}),
+        "scaled": (d, packed, {"scale_factor": np.float32(0.5)}),
+        "counts": (d, counts, {"missing_value": np.int32(-1)}),
+    })
+    return path, f, clean, packed, counts
+
+
+def test_cf_mask_and_scale_decoding(tmp_path):
+    (path, f, clean, packed, counts) = _cf_file(tmp_path)
+    ds = open_dataset(path)
+    filled = ds["filled"]
+    assert np.isnan(filled.values[1, 0, 2, 3]) and np.isnan(filled.values).sum() == 1 and filled.dtype == np.float32
+    keep = ~np.isnan(filled.values)
+    np.testing.assert_array_equal(filled.values[keep], f[keep])
+    assert filled.attrs == {"units": "K"}                    # the CF keys move out of attrs, as in xarray
+    # a fill value that never occurs leaves the variable as the file's own big-endian bytes (raw upload path)
+    assert ds["clean"].raw_values.dtype.byteorder == ">" and ds["clean"].attrs == {}
+    np.testing.assert_array_equal(ds["clean"].values, clean)
+    p = ds["packed"]
+    assert p.dtype == np.float64 and np.isnan(p.values[0, 0, 0, 0]) and np.isnan(p.values).sum() == 1
+    ok = ~np.isnan(p.values)
+    np.testing.assert_allclose(p.values[ok], packed[ok].astype(np.float64) * 0.01 + 273.15, rtol=0, atol=1e-12)
+    s = ds["scaled"]
+    assert s.dtype == np.float32
+    np.testing.assert_array_equal(s.values, packed.astype(np.float32) * np.float32(0.5))
+    c = ds["counts"]
+    assert c.dtype == np.float64 and np.isnan(c.values[2, 0, 1, 1]) and np.isnan(c.values).sum() == 1
+    # stored values on request
+    raw = open_dataset(path, mask_and_scale=False)
+    assert raw["filled"].values[1, 0, 2, 3] == -9999.0 and raw["packed"].dtype == np.int16
+    assert raw["packed"].attrs["scale_factor"] == 0.01
+    # and through the multi-file entry point the CLIs use
+    assert np.isnan(open_mfdataset([path, path], concat_dim="box")["filled"].values).sum() == 2
+
+
+def test_integers_are_never_narrowed_silently(tmp_path):
+    path = str(tmp_path / "ints.nc")
+    big = np.array([2 ** 40, -5, 7], dtype=np.int64)
+    netcdf3.write(path, {"x": 3, "y": 2}, {
+        "u8": (("y",), np.array([200, 255], dtype=np.uint8), {}),
+        "u16": (("y",), np.array([40000, 65535], dtype=np.uint16), {}),
+        "u32": (("y",), np.array([3, 2 ** 31 - 1], dtype=np.uint32), {}),
+        "u32big": (("y",), np.array([3, 2 ** 32 - 1], dtype=np.uint32), {}),
+        "i64": (("x",), np.array([1, -2, 3], dtype=np.int64), {}),
+        "i64big": (("x",), big, {}),
+    })
+    with netcdf3.File(path) as f:
+        got = {k: v.native() for k, v in f.variables.items()}
+    np.testing.assert_array_equal(got["u8"], [200, 255])
+    assert got["u8"].dtype == np.int16
+    np.testing.assert_array_equal(got["u16"], [40000, 65535])
+    assert got["u16"].dtype == np.int32
+    assert got["u32"].dtype == np.int32 and got["u32"][1] == 2 ** 31 - 1
+    assert got["u32big"].dtype == np.float64 and got["u32big"][1] == 2 ** 32 - 1
+    assert got["i64"].dtype == np.int32
+    assert got["i64big"].dtype == np.float64
+    np.testing.assert_array_equal(got["i64big"], big.astype(np.float64))
+    with pytest.raises(netcdf3.NetCDFError, match="fit neither"):
+        netcdf3.write(path, {"x": 1}, {"v": (("x",), np.array([2 ** 60 + 1], dtype=np.int64), {})})
+    with pytest.raises(netcdf3.NetCDFError, match="zero-length"):
+        netcdf3.write(path, {"x": 0}, {"v": (("x",), np.zeros(0, dtype=np.float32), {})})
+
+
+@pytest.mark.gpu
+def test_filled_pixel_reaches_dsdataset_as_nan(tmp_path):
+    """a _FillValue pixel must raise the reference's NaN error (ds_dataset.py:43-46,56-58), not be trained on"""
+    from cae_tools_amd.models.ds_dataset import DSDataset
+    (path, *_rest) = _cf_file(tmp_path)
+    ds = open_dataset(path)
+    with pytest.raises(ValueError, match="input variable filled contains 1 NaN values"):
+        DSDataset(ds, ["filled"], "clean")
+    with pytest.raises(ValueError, match="output variable contains 1 NaN values"):
+        DSDataset(ds, ["clean"], "filled")
+    ok = DSDataset(ds, ["clean", "scaled"], "clean")            # decoded (scaled) variables load like any other
+    assert ok.get_input_shape() == (2, 4, 4)
+
+
 @pytest.mark.gpu
 def test_big_endian_slab_is_swapped_on_the_gpu(tmp_path, monkeypatch):
     import torch
