@@ -9,8 +9,9 @@ Workload (BASELINE.json configs[1], "cfg2"): ConvAEModel 'conv', 16x16 -> 256x25
 fc_size 128 / latent 32 (API defaults, conv_ae_model.py:36), batch 64 per GPU, synthetic data,
 random-init weights (torch.manual_seed(0)).  One step = one iteration of __train_epoch
 (conv_ae_model.py:189-200): train-mode forward, MSE, backward, Adam.  Inputs are resident in
-HBM before the timed region.  N > 1: one process per GPU, every rank its own 64-sample batches
-(weak scaling, global batch 64*N), one RCCL all-reduce of the flat fp32 gradient per step.
+HBM before the timed region.  N > 1: one process per GPU, global batch 64*N (weak scaling: 64 samples
+per GPU per step), rank r takes rows [64r, 64r+64) of every frozen global batch; the gradients are
+all-reduced inside libcae_hip (RCCL, two buckets, second stream, captured in the step graph).
 
 Prints ONE JSON line on rank 0.
 """
@@ -158,10 +159,14 @@ def main():
     eng = HipEngine(spec, FC, LATENT, max_batch=BATCH, device=device, graph=os.environ.get("CAE_GRAPH", "1") != "0")
     eng.load_state(enc.state_dict(), dec.state_dict())
     eng.set_hyper(lr=1e-3, weight_decay=1e-5)
-    x, t = synthetic(N_TRAIN, device, 1234 + rank)
+    # every rank holds the same N_TRAIN samples and the same frozen shuffle (what ConvAEModel.train does under data
+    # parallelism): a global batch is 64 * world consecutive rows of the permutation, rank r takes rows [64 r, 64 r + 64)
+    x, t = synthetic(N_TRAIN, device, 1234)
     eng.set_dataset(0, x, t)
-    perm = eng.upload_perm(np.random.default_rng(99 + rank).permutation(N_TRAIN))
-    steps_per_epoch = N_TRAIN // BATCH
+    perm = eng.upload_perm(np.random.default_rng(99).permutation(N_TRAIN))
+    global_batch = BATCH * world
+    steps_per_epoch = N_TRAIN // global_batch
+    dp_graph = None
 
     if dist is None:
         def run(nsteps):
@@ -171,13 +176,19 @@ def main():
                 eng.enqueue_train_steps(0, perm, n * BATCH, BATCH, 0)
                 done += n
     else:
-        from cae_tools_amd.dp import DataParallel
-        dp = DataParallel(eng, dist, sync_bn=args.sync_bn)
+        from cae_tools_amd.dp import DataParallel, shard_bounds
+        dp = DataParallel(eng, dist, sync_bn=args.sync_bn)      # joins the library's RCCL communicator (self-tested)
         dp.broadcast_parameters(0)
+        dp_graph = eng.dp_graph_capture()
+        (lo, hi) = shard_bounds(global_batch, world, rank)
 
         def run(nsteps):
-            for s in range(nsteps):
-                dp.train_step(0, perm, (s % steps_per_epoch) * BATCH, BATCH)
+            done = 0
+            while done < nsteps:
+                n = min(steps_per_epoch, nsteps - done)      # one epoch's steps: ONE call = one graph replay
+                eng.set_cursor(lo, 0)
+                eng.dp_train_steps(0, perm, hi - lo, global_batch, args.sync_bn, n)
+                done += n
 
     def barrier():
         if dist is not None:
@@ -211,7 +222,10 @@ def main():
             "config": {"workload": "cfg2: ConvAEModel 'conv' 16x16->256x256 1-ch, fc128/latent32, batch 64 per GPU, "
                                    "train step = fwd+MSE+bwd+Adam, BatchNorm batch stats per GPU",
                        "global_batch": BATCH * world, "n_train": N_TRAIN, "params": 112271,
-                       "parallelism": (f"dp{world}" + ("+syncbn" if args.sync_bn else "")) if dist is not None else "single"},
+                       "parallelism": (f"dp{world}" + ("+syncbn" if args.sync_bn else "")) if dist is not None else "single",
+                       "dp_collectives": None if dist is None else
+                       ("RCCL all-reduce of 2 gradient buckets on a second stream, " +
+                        ("captured in the step graph" if dp_graph else "plain launches"))},
             "step_roofline": {"algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE,
                               "achieved_GBs": value / world * ALGO_BYTES_PER_IMAGE / 1e9,
                               "frac_of_8TBs": value / world * ALGO_BYTES_PER_IMAGE / 1e9 / HBM_PEAK_GBS},

@@ -55,6 +55,15 @@ SIGNATURES = {
     "cae_forward_backward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
     "cae_adam_step": (C.c_int, [_P]),
     "cae_forward_backward_sync": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, ALLREDUCE_FN, _P]),
+    "cae_dp_unique_id": (C.c_int, [_P]),
+    "cae_dp_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "cae_dp_shutdown": (C.c_int, [_P]),
+    "cae_dp_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "cae_dp_broadcast_state": (C.c_int, [_P, C.c_int, C.c_int]),
+    "cae_dp_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "cae_dp_train_steps": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "cae_dp_eval_steps": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "cae_dp_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cae_eval_step": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "cae_score": (C.c_int, [_P, _P, C.c_int, _P]),
     "cae_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),

@@ -23,11 +23,18 @@ def build_parser():
     p.add_argument("--prediction-variable", help="name of the prediction variable to create in output data",
                    default="model_output")
     p.add_argument("--mask-variable", type=str, help="name of the mask variable", default=None)
+    p.add_argument("--gpus", type=int, default=1, help="build-only: shard the cases over this many GPUs of the node")
     return p
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    from ._launch import maybe_spawn_ranks
+    rc = maybe_spawn_ranks("cae_tools_amd.cli.apply_cae", args.gpus, argv)   # before anything touches the GPU
+    if rc is not None:
+        if rc:
+            raise SystemExit(rc)
+        return
     with open(os.path.join(args.model_folder, "parameters.json")) as f:
         parameters = json.loads(f.read())
     kinds = {"ConvAEModel": ConvAEModel, "UNET": UNET, "VarAEModel": VarAEModel, "LinearModel": LinearModel}
@@ -56,7 +63,8 @@ def main(argv=None):
                                       dims=(case_dimension, "channel", "y", "x"))
     print("Applying model for %d cases" % score_ds[case_dimension].shape[0])
     mt.apply(score_ds, input_variable_names, args.prediction_variable, mask_variable_name=args.mask_variable)
-    score_ds.to_netcdf(args.output_path)
+    if int(os.environ.get("RANK", "0")) == 0:       # every rank holds all predictions (all-gather); rank 0 writes
+        score_ds.to_netcdf(args.output_path)
 
 
 if __name__ == "__main__":

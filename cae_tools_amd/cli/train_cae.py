@@ -1,8 +1,10 @@
 """train_cae — command line front end with the reference's flags (src/cae_tools/cli/train_cae.py:19-53).
 
-Only --method conv is implemented by this package (the ConvAEModel hot path); the other method
-names are accepted by the parser, as in the reference, and rejected with a clear message (the
-reference itself constructs no model for var/vae/unet_res/srcnn_res/resunet_gan: SURVEY.md fact 3).
+--method conv (ConvAEModel, the hot path), unet (UNET), var (VarAEModel: the reference's default method, whose model
+source is missing there - this build's own definition, PARITY UNPINNED) and linear (LinearModel) are
+implemented; the other method names are accepted by the parser, as in the reference, and rejected with a clear message
+(the reference itself constructs no model for vae/unet_res/srcnn_res/resunet_gan: SURVEY.md fact 3).
+Build-only flags: --gpus N (data-parallel ConvAE training over N GPUs of this node, one process per GPU) and --local-bn.
 """
 import argparse
 import json
@@ -58,6 +60,10 @@ def build_parser():
     p.add_argument("--chunk-size", type=int, help="chunk size for xarray", default=1000)
     p.add_argument("--include-coasts", help="include coastal areas", default=False)
     p.add_argument("--mask-variable", type=str, help="name of the mask variable", default=None)
+    # build-only: the reference trains on one device
+    p.add_argument("--gpus", type=int, default=1, help="train data-parallel on this many GPUs of the node (conv method)")
+    p.add_argument("--local-bn", action="store_true", help="with --gpus N: per-GPU BatchNorm statistics instead of statistics "
+                   "over the global batch (faster; no longer the single-device arithmetic)")
     return p
 
 
@@ -74,6 +80,12 @@ def broadcast_case_variables(ds, variables, case_dimension):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    from ._launch import maybe_spawn_ranks
+    rc = maybe_spawn_ranks("cae_tools_amd.cli.train_cae", args.gpus, argv)   # before anything touches the GPU
+    if rc is not None:
+        if rc:
+            raise SystemExit(rc)
+        return
     train_ds = open_mfdataset(args.train_inputs, concat_dim="box", combine="nested")
     test_ds = open_mfdataset(args.test_inputs, concat_dim="box", combine="nested")
     case_dimension = train_ds[args.output_variable].dims[0]
@@ -121,6 +133,8 @@ def main(argv=None):
                 spec.load(json.loads(f.read()))
                 mt.spec = spec
 
+    if hasattr(mt, "sync_bn"):
+        mt.sync_bn = not args.local_bn
     start_time = time.time()
     print("Ready for training process")
     mt.train(args.input_variables, args.output_variable, training_ds=train_ds, testing_ds=test_ds,

@@ -19,6 +19,7 @@
 #include "kernels_gemm.h"
 #include "kernels_igemm.h"
 #include "kernels_head.h"
+#include "dp_comm.h"
 
 using namespace cae;
 
@@ -112,7 +113,17 @@ struct cae_engine {
     struct ProfRec { const char* name; int layer; double bytes; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof;
     // key: (op, which, batch, global_batch, perm)
-    std::map<std::tuple<int, int, int, int, const void*, int>, hipGraphExec_t> graphs;
+    std::map<std::tuple<int, int, int, int, const void*, int, int>, hipGraphExec_t> graphs;
+
+    // data-parallel state (cae_dp_init): one RCCL communicator, a second stream for the gradient buckets, fork/join events
+    int dp_world = 0, dp_rank = 0;
+    RcclApi::comm_t dp_comm = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool dp_graph_ok = true;            // RCCL calls captured inside the step graph (checked by cae_dp_init's self-test)
+    std::vector<int> sync_order;        // BatchNorm tables in the order a SyncBN step all-reduces them
+    size_t sync_pos = 0;
+    int64_t bucket_split = 0;           // gradient buckets: [bucket_split, n_param) first (decoder), [0, bucket_split) last
 
     StepState* state() const { return reinterpret_cast<StepState*>(ws + off_state); }
     double* losses() const { return reinterpret_cast<double*>(ws + off_losses); }
@@ -225,7 +236,7 @@ int wgrad_ppb(int64_t positions, int64_t nweights) {
     return (int)ppb;
 }
 
-enum Op { OP_TRAIN = 1, OP_FWDBWD = 2, OP_EVAL = 3, OP_ADAM = 4 };
+enum Op { OP_TRAIN = 1, OP_FWDBWD = 2, OP_EVAL = 3, OP_ADAM = 4, OP_DP_TRAIN = 5 };
 
 StepTail step_tail_of(cae_engine* e, int batch_inc, int slot_inc) {
     StepTail t;
@@ -281,11 +292,33 @@ struct StepArgs {
     void* sync_user = nullptr;
     int world = 1;
     int nsteps = 1;        // consecutive steps of the same batch size in one captured graph
+    // data-parallel step inside the library (cae_dp_train_step): gradient buckets all-reduced by RCCL on the second stream;
+    // dp_sync additionally all-reduces every BatchNorm sum table in-stream (SyncBN) instead of calling sync_fn
+    bool dp = false, dp_sync = false;
+    int cursor_inc = -1;   // samples the cursor moves per step (-1: batch; the global batch under data parallelism)
+    bool syncing() const { return sync_fn != nullptr || dp_sync; }
+    int inc() const { return cursor_inc >= 0 ? cursor_inc : batch; }
 };
 
+#define NCCL_TRY(expr)                                                                                            \
+    do {                                                                                                          \
+        int _r = (expr);                                                                                          \
+        if (_r != 0) return fail(CAE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
 int sync_bn_table(cae_engine* e, const StepArgs& a, int bn_index) {
-    if (!a.sync_fn) return CAE_OK;
+    if (!a.syncing()) return CAE_OK;
     const int64_t n = (int64_t)kStatShards * e->bn_channels[bn_index] * 4;
+    if (a.dp_sync) {
+        // every rank must issue the same collectives in the same order: the order is a property of the model (sync_order),
+        // and a step that deviates from it is an error here rather than a hang over there
+        if (e->sync_pos >= e->sync_order.size() || e->sync_order[e->sync_pos] != bn_index)
+            return fail(CAE_ERR_STATE, "SyncBN: table %d all-reduced out of order (position %zu)", bn_index, e->sync_pos);
+        e->sync_pos++;
+        NCCL_TRY(rccl().AllReduce(e->bn_stats(bn_index), e->bn_stats(bn_index), (size_t)n, RcclApi::kFloat64, RcclApi::kSum,
+                                  e->dp_comm, e->stream));
+        return CAE_OK;
+    }
     if (a.sync_fn(a.sync_user, e->bn_stats(bn_index), n) != 0)
         return fail(CAE_ERR_STATE, "the all-reduce callback failed for BatchNorm table %d", bn_index);
     return CAE_OK;
@@ -413,7 +446,7 @@ void s2_bwd_dispatch(const ConvLayer& L, const S2Bwd& a, hipStream_t s) {
 // the batch does not fit (the caller then runs the per-layer launches).
 bool head_plan(const cae_engine* e, const StepArgs& a, HeadArgs& h, size_t& lds_bytes) {
     static const int enabled = env_int("CAE_HEAD", 1);   // env: A/B measurements only
-    if (!enabled || !e->use_s2 || a.sync_fn || (int)e->enc.size() > kHeadMaxEnc) return false;
+    if (!enabled || !e->use_s2 || a.syncing() || (int)e->enc.size() > kHeadMaxEnc) return false;
     memset(&h, 0, sizeof h);
     h.B = a.batch;
     h.n_enc = (int)e->enc.size();
@@ -541,7 +574,7 @@ void head_lds_attr(K kernel, size_t bytes) {
 // k_tail_bwd (kernels_head.h): Linear 2..0 backward in one launch.  False: run the per-layer pair launches.
 bool tail_plan(const cae_engine* e, const StepArgs& a, TailArgs& t, size_t& lds_bytes) {
     static const int enabled = env_int("CAE_TAIL", 1);   // env: A/B measurements only
-    if (!enabled || !e->use_s2 || a.sync_fn) return false;
+    if (!enabled || !e->use_s2 || a.syncing()) return false;
     memset(&t, 0, sizeof t);
     const ConvLayer& P = e->enc.back();
     double* acc = e->gradacc();
@@ -602,6 +635,70 @@ bool tail_plan(const cae_engine* e, const StepArgs& a, TailArgs& t, size_t& lds_
     // weight-gradient shares: M = nout, N = nin + 1, K = 16 rows
     for (int i = 0; i < 3; i++) t.sp_w[i] = stage_split(((e->fc[2 - i].nout + 15) / 16) * ((e->fc[2 - i].nin + 16) / 16), 16);
     return true;
+}
+
+// ---- data-parallel gradient exchange (cae_dp_train_step) -------------------------------------------
+// Two buckets in the order backward completes them: [bucket_split, n_param) = Linear 3 and the decoder convolutions, ready
+// as soon as Linear 3's backward has run, narrowed to fp32 and all-reduced on the second stream while the main stream
+// still runs Linear 2..0 and the encoder backward; then [0, bucket_split).  Both on ONE communicator used from ONE stream.
+// Under SyncBN every collective (tables and buckets) stays on the main stream instead: the tables are on the critical
+// path anyway, and one communicator is never driven from two streams at once.
+StepTail narrow_tail(cae_engine* e, bool with_step_tail, int batch_inc) {
+    StepTail t = step_tail_of(e, batch_inc, 1);
+    if (!with_step_tail) {
+        t.zero_extra = nullptr;
+        t.zero_extra_n = 0;
+        t.st = nullptr;
+    }
+    return t;
+}
+
+int dp_allreduce_grads(cae_engine* e, int64_t lo, int64_t hi, hipStream_t on) {
+    if (hi <= lo) return CAE_OK;
+    NCCL_TRY(rccl().AllReduce(e->grads + lo, e->grads + lo, (size_t)(hi - lo), RcclApi::kFloat32, RcclApi::kSum, e->dp_comm, on));
+    return CAE_OK;
+}
+
+int dp_first_bucket(cae_engine* e, const StepArgs& a) {
+    if (!a.dp) return CAE_OK;
+    const int64_t lo = e->bucket_split, hi = e->n_param;
+    hipStream_t on = a.dp_sync ? e->stream : e->comm_stream;
+    if (!a.dp_sync) {
+        HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
+    }
+    {
+        ProfScope _p(e, "dp_narrow_bucket0", 0, 12.0 * (hi - lo), on);
+        hipLaunchKernelGGL(k_narrow_range, dim3(grid1(hi - lo)), dim3(256), 0, on, (long long)lo, (long long)hi, e->grads,
+                           e->shard_segs(), narrow_tail(e, false, 0));
+    }
+    return dp_allreduce_grads(e, lo, hi, on);
+}
+
+// after the last backward kernel: second bucket, join, Adam from the reduced fp32 gradients
+int dp_finish_step(cae_engine* e, const StepArgs& a) {
+    hipStream_t s = e->stream;
+    const int64_t lo = 0, hi = e->bucket_split;
+    {
+        ProfScope _p(e, "dp_narrow_bucket1", 0, 12.0 * (hi - lo));
+        hipLaunchKernelGGL(k_narrow_range, dim3(grid1(hi - lo > 0 ? hi - lo : 1)), dim3(256), 0, s, (long long)lo, (long long)hi,
+                           e->grads, e->shard_segs(), narrow_tail(e, true, a.inc()));
+    }
+    if (a.dp_sync) {
+        if (int rc = dp_allreduce_grads(e, lo, hi, s)) return rc;
+    } else {
+        HIP_TRY(hipEventRecord(e->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
+        if (int rc = dp_allreduce_grads(e, lo, hi, e->comm_stream)) return rc;
+        HIP_TRY(hipEventRecord(e->ev_join, e->comm_stream));
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
+    }
+    StepTail none;
+    memset(&none, 0, sizeof none);
+    ProfScope _p(e, "adam", 0, 28.0 * e->n_param);
+    hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
+                       (const float*)e->grads, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(), none, 0);
+    return CAE_OK;
 }
 
 int launch_forward(cae_engine* e, const StepArgs& a) {
@@ -714,7 +811,9 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             }
         } else {
             memset(&ep, 0, sizeof ep);
-            ep.inv_count = (float)(1.0 / ((double)a.bn_batch * L.cout * L.hout * L.wout));
+            // mean over the GLOBAL batch: each rank contributes sum(local terms) / global count, and the SUM all-reduce of the
+            // gradients then yields the global-mean gradient (global_batch == batch on a single device)
+            ep.inv_count = (float)(1.0 / ((double)a.global_batch * L.cout * L.hout * L.wout));
             ep.losses = e->losses();
             ep.perm = a.perm;
             ep.use_cursor = a.use_cursor ? 1 : 0;
@@ -978,6 +1077,8 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
         const bool fused_tail = tail_plan(e, a, tail, tail_lds);
         for (int i = 3; i >= 0; i--) {
             const FcLayer& F = e->fc[i];
+            if (i == 2)   // every decoder conv gradient and Linear 3's are complete: the first gradient bucket can leave
+                if (int rc = dp_first_bucket(e, a)) return rc;
             if (fused_tail && i == 2) {
                 double bytes = 0;
                 for (int j = 0; j < 3; j++)
@@ -1090,7 +1191,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             ain = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
             bna = bn_of(e, P, BN_SAVED, 0, 0);
         }
-        if (l > 0 && e->use_s2 && !a.sync_fn) {
+        if (l > 0 && e->use_s2 && !a.syncing()) {
             // weight gradient and input gradient share only their inputs: one launch (kernels_generic.h k_conv_bwd_pair)
             const ConvLayer& P = e->enc[l - 1];
             const int64_t nw = (int64_t)L.cin * L.cout * L.kh * L.kw;
@@ -1169,7 +1270,25 @@ int launch_one(cae_engine* e, int op, const StepArgs& a) {
     {   // while profiling: one EMPTY bracket per step = what an event pair itself adds to every bracketed launch
         ProfScope _cal(e, "event_pair", -1, 0.0);
     }
-    if (op == OP_TRAIN || op == OP_FWDBWD) {
+    if (op == OP_DP_TRAIN) {
+        e->sync_pos = 0;
+        if (a.batch > 0) {
+            int rc = launch_forward(e, a);
+            if (rc) return rc;
+            rc = launch_backward(e, a);
+            if (rc) return rc;
+        } else {
+            // a rank whose shard of a short last batch is empty: no kernels, but every collective of the step in order
+            hipLaunchKernelGGL(k_bump_adam, dim3(1), dim3(1), 0, s, e->state());
+            if (a.dp_sync)
+                for (int bn : e->sync_order)
+                    if (int rc = sync_bn_table(e, a, bn)) return rc;
+            if (int rc = dp_first_bucket(e, a)) return rc;
+        }
+        if (a.dp_sync && e->sync_pos != e->sync_order.size())
+            return fail(CAE_ERR_STATE, "SyncBN: %zu of %zu tables all-reduced", e->sync_pos, e->sync_order.size());
+        if (int rc = dp_finish_step(e, a)) return rc;
+    } else if (op == OP_TRAIN || op == OP_FWDBWD) {
         // the accumulators were zeroed by the previous step's last kernel (k_adam / k_acc_to_f32) or by
         // the caller's zero-filled workspace on the very first step
         int rc = launch_forward(e, a);
@@ -1180,15 +1299,15 @@ int launch_one(cae_engine* e, int op, const StepArgs& a) {
             ProfScope _p(e, "adam", 0, 32.0 * e->n_param);
             hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
                                (const float*)nullptr, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(),
-                               step_tail_of(e, a.batch, 1), 0);
+                               step_tail_of(e, a.inc(), 1), 0);
         } else {
             hipLaunchKernelGGL(k_acc_to_f32, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->grads,
-                               e->shard_segs(), step_tail_of(e, a.batch, 1));
+                               e->shard_segs(), step_tail_of(e, a.inc(), 1));
         }
     } else if (op == OP_EVAL) {
         int rc = launch_forward(e, a);
         if (rc) return rc;
-        if (a.use_cursor) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), a.batch, 1, 0);
+        if (a.use_cursor) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, e->state(), a.inc(), 1, 0);
     } else if (op == OP_ADAM) {
         StepTail none;
         memset(&none, 0, sizeof none);
@@ -1205,7 +1324,7 @@ int launch_one(cae_engine* e, int op, const StepArgs& a) {
 int run_op(cae_engine* e, int op, const StepArgs& a, bool cacheable) {
     // the legacy NULL stream cannot be captured: plain launches there
     if (!e->graph_mode || !cacheable || e->stream == nullptr || e->profiling) return launch_op(e, op, a);
-    auto key = std::make_tuple(op, a.which, a.batch, a.global_batch, (const void*)a.perm, a.nsteps);
+    auto key = std::make_tuple(op, a.which, a.batch, a.global_batch, (const void*)a.perm, a.nsteps, a.cursor_inc);
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -1346,6 +1465,15 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
     e->n_param = align_up(e->n_param, 4);
     e->n_buf = align_up(e->n_buf, 4);
     e->n_bn = bn;
+    // data parallelism: bucket boundary and the SyncBN collective order (forward: producers in layer order; backward: the
+    // table of a layer's INPUT BatchNorm after that layer's input-gradient kernel) - see launch_forward / launch_backward
+    e->bucket_split = e->fc[3].w_off;
+    for (auto& L : e->enc) e->sync_order.push_back(L.bn_index);
+    for (auto& L : e->dec)
+        if (L.has_bn) e->sync_order.push_back(L.bn_index);
+    for (int l = n_dec - 1; l >= 1; l--) e->sync_order.push_back(e->dec[l - 1].bn_index);
+    e->sync_order.push_back(e->enc.back().bn_index);
+    for (int l = n_enc - 1; l >= 1; l--) e->sync_order.push_back(e->enc[l - 1].bn_index);
 
     // ---- sharded accumulators for the layers the stride-2 kernels can take
     {
@@ -1421,6 +1549,7 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
 void cae_engine_destroy(cae_engine* e) {
     if (!e) return;
     e->drop_graphs();
+    (void)cae_dp_shutdown(e);
     delete e;
 }
 
@@ -1548,6 +1677,200 @@ int cae_forward_backward_sync(cae_engine* e, int which, const int32_t* perm, int
     a.sync_user = user;
     a.world = world;
     return run_op(e, OP_FWDBWD, a, false);   // plain launches: the callback runs between them
+}
+
+// ---- data parallelism inside the library ---------------------------------------------------------
+
+int cae_dp_unique_id(void* id128_host) {
+    if (!id128_host) return fail(CAE_ERR_ARG, "cae_dp_unique_id: null pointer");
+    if (const char* why = rccl().load()) return fail(CAE_ERR_STATE, "RCCL: %s", why);
+    RcclApi::UniqueId id;
+    NCCL_TRY(rccl().GetUniqueId(&id));
+    memcpy(id128_host, id.internal, sizeof id.internal);
+    return CAE_OK;
+}
+
+int cae_dp_shutdown(cae_engine* e) {
+    if (!e) return fail(CAE_ERR_ARG, "null engine");
+    if (e->dp_comm) {
+        e->drop_graphs();
+        if (e->stream) (void)hipStreamSynchronize(e->stream);
+        if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
+        (void)rccl().CommDestroy(e->dp_comm);
+        e->dp_comm = nullptr;
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
+    e->ev_fork = e->ev_join = nullptr;
+    e->comm_stream = nullptr;
+    e->dp_world = 0;
+    return CAE_OK;
+}
+
+namespace {
+
+// cae_dp_init's self-test: the fork / all-reduce / join pattern of a data-parallel step, captured into a hipGraph and
+// replayed twice on ones: every element must read world^2 afterwards.  A capture or replay ERROR switches the engine to
+// plain launches for data-parallel steps (dp_graph_ok = false); wrong VALUES fail the init.
+int dp_self_test(cae_engine* e) {
+    hipStream_t s = e->stream;
+    const int64_t n = e->n_param, mid = e->bucket_split;
+    auto body = [&]() -> int {
+        HIP_TRY(hipEventRecord(e->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
+        if (int rc = dp_allreduce_grads(e, mid, n, e->comm_stream)) return rc;
+        if (int rc = dp_allreduce_grads(e, 0, mid, e->comm_stream)) return rc;
+        HIP_TRY(hipEventRecord(e->ev_join, e->comm_stream));
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
+        return CAE_OK;
+    };
+    auto fill = [&]() {
+        hipLaunchKernelGGL(k_fill_f32, dim3(grid1(n)), dim3(256), 0, s, e->grads, (long long)n, 1.0f);
+    };
+    auto check = [&](double want, const char* what) -> int {
+        float got[2] = {0.f, 0.f};
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(&got[0], e->grads, sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&got[1], e->grads + n - 1, sizeof(float), hipMemcpyDeviceToHost));
+        if ((double)got[0] != want || (double)got[1] != want)
+            return fail(CAE_ERR_STATE, "RCCL self-test (%s): all-reduce of ones gave %g / %g, expected %g", what, got[0], got[1], want);
+        return CAE_OK;
+    };
+    // plain launches first: RCCL sets its channels up on the first collective of each size class, outside any capture
+    fill();
+    if (int rc = body()) return rc;
+    if (int rc = check((double)e->dp_world, "plain")) return rc;
+    static const int want_graph = env_int("CAE_DP_GRAPH", 1);   // env: 0 keeps RCCL calls out of captured graphs
+    e->dp_graph_ok = want_graph != 0 && s != nullptr;
+    if (!e->dp_graph_ok) return CAE_OK;
+    fill();
+    HIP_TRY(hipStreamSynchronize(s));
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+        const int rc = body();
+        const hipError_t ce = hipStreamEndCapture(s, &graph);
+        ok = rc == CAE_OK && ce == hipSuccess && graph != nullptr;
+    }
+    if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (ok) ok = hipGraphLaunch(exec, s) == hipSuccess && hipGraphLaunch(exec, s) == hipSuccess;
+    if (ok) ok = hipStreamSynchronize(s) == hipSuccess;
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    if (!ok) {
+        e->dp_graph_ok = false;   // data-parallel steps run as plain launches; the compute path is the same
+        fprintf(stderr, "libcae_hip: RCCL collectives could not be captured into a hipGraph here; data-parallel steps use plain launches\n");
+        return CAE_OK;
+    }
+    return check((double)e->dp_world * e->dp_world, "captured");
+}
+
+}  // namespace
+
+int cae_dp_init(cae_engine* e, int world, int rank, const void* id128_host) {
+    if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+    if (world < 1 || rank < 0 || rank >= world || !id128_host) return fail(CAE_ERR_ARG, "cae_dp_init: bad argument");
+    if (!e->stream) return fail(CAE_ERR_STATE, "cae_dp_init needs a non-default stream (cae_set_stream)");
+    if (const char* why = rccl().load()) return fail(CAE_ERR_STATE, "RCCL: %s", why);
+    (void)cae_dp_shutdown(e);
+    RcclApi::UniqueId id;
+    memcpy(id.internal, id128_host, sizeof id.internal);
+    NCCL_TRY(rccl().CommInitRank(&e->dp_comm, world, id, rank));
+    e->dp_world = world;
+    e->dp_rank = rank;
+    HIP_TRY(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    // warm the size classes a step uses: the two gradient buckets (self-test) and the BatchNorm tables (fp64, on the
+    // main stream), on the gradient arena as scratch - its contents mean nothing between steps
+    if (int rc = dp_self_test(e)) return rc;
+    for (int c : e->bn_channels) {
+        const size_t nd = (size_t)kStatShards * c * 4;
+        if ((int64_t)nd * 2 > e->n_param) continue;
+        NCCL_TRY(rccl().AllReduce(e->grads, e->grads, nd, RcclApi::kFloat64, RcclApi::kSum, e->dp_comm, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipStreamSynchronize(e->comm_stream));
+    return CAE_OK;
+}
+
+int cae_dp_info(const cae_engine* e, int* world, int* rank, int* graph_capture) {
+    if (!e) return fail(CAE_ERR_ARG, "null engine");
+    if (world) *world = e->dp_world;
+    if (rank) *rank = e->dp_rank;
+    if (graph_capture) *graph_capture = e->dp_comm && e->dp_graph_ok && e->graph_mode ? 1 : 0;
+    return CAE_OK;
+}
+
+int cae_dp_broadcast_state(cae_engine* e, int root, int what) {
+    if (!e || !e->dp_comm) return fail(CAE_ERR_STATE, "cae_dp_init has not been called");
+    if (root < 0 || root >= e->dp_world) return fail(CAE_ERR_ARG, "cae_dp_broadcast_state: bad root");
+    hipStream_t s = e->stream;
+    auto bc = [&](float* p, int64_t n) -> int {
+        if (n > 0) NCCL_TRY(rccl().Broadcast(p, p, (size_t)n, RcclApi::kFloat32, root, e->dp_comm, s));
+        return CAE_OK;
+    };
+    if (what & 1) if (int rc = bc(e->params, e->n_param)) return rc;
+    if (what & 2) if (int rc = bc(e->bufs, e->n_buf)) return rc;
+    if (what & 4) {
+        if (int rc = bc(e->m, e->n_param)) return rc;
+        if (int rc = bc(e->v, e->n_param)) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return CAE_OK;
+}
+
+int cae_dp_train_steps(cae_engine* e, int which, const int32_t* perm, int batch, int global_batch, int sync_bn, int nsteps) {
+    if (!e || !e->dp_comm) return fail(CAE_ERR_STATE, "cae_dp_init has not been called");
+    if (batch == 0) {   // an empty shard (a last batch shorter than the number of ranks): collectives only
+        if (!e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+    } else if (int rc = check_ready(e, which, batch, true)) {
+        return rc;
+    }
+    if (global_batch < batch || global_batch < 1) return fail(CAE_ERR_ARG, "global_batch %d < batch %d", global_batch, batch);
+    if (nsteps < 1 || nsteps > 4096) return fail(CAE_ERR_ARG, "nsteps %d outside [1, 4096]", nsteps);
+    StepArgs a{which, perm, batch, global_batch, sync_bn ? global_batch : batch, true, true, nullptr, nullptr, true};
+    a.nsteps = nsteps;
+    a.dp = true;
+    a.dp_sync = sync_bn != 0;
+    a.world = sync_bn ? e->dp_world : 1;   // BatchNorm parameter gradients come from GLOBAL sums under SyncBN: 1/world each
+    a.cursor_inc = global_batch;           // consecutive steps of a rank are one GLOBAL batch apart in the frozen permutation
+    return run_op(e, OP_DP_TRAIN, a, e->dp_graph_ok);
+}
+
+int cae_dp_train_step(cae_engine* e, int which, const int32_t* perm, int batch, int global_batch, int sync_bn) {
+    return cae_dp_train_steps(e, which, perm, batch, global_batch, sync_bn, 1);
+}
+
+int cae_dp_eval_steps(cae_engine* e, int which, const int32_t* perm, int batch, int global_batch, int nsteps) {
+    if (!e || !e->dp_comm) return fail(CAE_ERR_STATE, "cae_dp_init has not been called");
+    if (global_batch < batch || global_batch < 1) return fail(CAE_ERR_ARG, "global_batch %d < batch %d", global_batch, batch);
+    if (nsteps < 1 || nsteps > 4096) return fail(CAE_ERR_ARG, "nsteps %d outside [1, 4096]", nsteps);
+    if (batch == 0) {   // empty shard: only the cursor and the loss slot move
+        if (!e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+        for (int i = 0; i < nsteps; i++) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, e->stream, e->state(), global_batch, 1, 0);
+        HIP_TRY(hipGetLastError());
+        return CAE_OK;
+    }
+    if (int rc = check_ready(e, which, batch, true)) return rc;
+    StepArgs a{which, perm, batch, global_batch, batch, false, true, nullptr, nullptr, true};
+    a.nsteps = nsteps;
+    a.cursor_inc = global_batch;
+    return run_op(e, OP_EVAL, a, true);
+}
+
+int cae_dp_read_losses(cae_engine* e, int first, int count, double* host_out) {
+    if (!e || !e->dp_comm) return fail(CAE_ERR_STATE, "cae_dp_init has not been called");
+    if (first < 0 || count < 0 || first + count > kLossSlots || !host_out) return fail(CAE_ERR_ARG, "bad loss range");
+    if (count == 0) return CAE_OK;
+    double* dev = e->losses() + (size_t)first * kStatShards;
+    // every rank's slot holds sum(local terms) / global count: the sum over ranks is the global-batch mean
+    NCCL_TRY(rccl().AllReduce(dev, dev, (size_t)count * kStatShards, RcclApi::kFloat64, RcclApi::kSum, e->dp_comm, e->stream));
+    return cae_read_losses(e, first, count, host_out);
 }
 
 int cae_adam_step(cae_engine* e) {

@@ -771,6 +771,25 @@ __global__ void k_acc_to_f32(long long n, float* __restrict__ g, ShardSegs ss, S
     if (i < n) g[i] = consume_grad(tl, ss, i);
 }
 
+// data-parallel path: the fp64 accumulators of parameters [lo, hi) -> the fp32 gradient arena (consumed and cleared), one
+// gradient bucket per launch; the launch for the last bucket also carries the step tail
+__global__ void k_narrow_range(long long lo, long long hi, float* __restrict__ g, ShardSegs ss, StepTail tl) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tl.zero_extra || tl.st) step_tail(tl, t, (long long)gridDim.x * 256);
+    const long long i = lo + t;
+    if (i < hi) g[i] = consume_grad(tl, ss, i);
+}
+
+__global__ void k_fill_f32(float* __restrict__ p, long long n, float v) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void k_scale_f64(double* __restrict__ p, long long n, double f) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] *= f;
+}
+
 // the optimiser step counter for the data-parallel path, where Adam runs as its own op
 __global__ void k_bump_adam(StepState* st) { st->adam_step += 1; }
 

@@ -346,6 +346,65 @@ class HipEngine(EnginePlan):
         check(self.lib.cae_adam_step(self.handle))
         self.adam_steps += 1
 
+    # ---- data parallelism inside the library (include/cae_hip.h, cae_dp_*) ------------------------
+    dp_world = 0
+    dp_rank = 0
+
+    def dp_init(self, dist, group=None):
+        """Join the library's RCCL communicator: rank 0 draws the 128-byte rendezvous id, torch.distributed (any
+        backend) carries it to the other ranks, cae_dp_init is the collective.  Returns True when data-parallel steps
+        replay from one hipGraph with the collectives captured inside."""
+        (world, rank) = (dist.get_world_size(group), dist.get_rank(group))
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            check(self.lib.cae_dp_unique_id(ident))
+        box = [ident.raw]
+        with torch.cuda.device(self.device):
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            check(self.lib.cae_dp_init(self.handle, world, rank, box[0]))
+        (self.dp_world, self.dp_rank) = (world, rank)
+        self._cursor = None
+        return self.dp_graph_capture()
+
+    def dp_graph_capture(self):
+        flag = C.c_int(0)
+        check(self.lib.cae_dp_info(self.handle, None, None, C.byref(flag)))
+        return bool(flag.value)
+
+    def dp_shutdown(self):
+        check(self.lib.cae_dp_shutdown(self.handle))
+        self.dp_world = 0
+
+    def dp_broadcast(self, root=0, params=True, buffers=True, moments=True):
+        """rank `root`'s weights / BatchNorm running statistics / Adam moments to every rank (blocking)"""
+        what = (1 if params else 0) | (2 if buffers else 0) | (4 if moments else 0)
+        check(self.lib.cae_dp_broadcast_state(self.handle, int(root), what))
+
+    def claim_slots(self, n):
+        return self._claim_slots(n)
+
+    def set_cursor(self, start, slot):
+        self._set_cursor(start, slot)
+
+    def dp_train_steps(self, which, perm_dev, batch, global_batch, sync_bn, nsteps=1):
+        """nsteps data-parallel optimiser steps: step k takes this rank's `batch` rows starting at cursor + k*global_batch"""
+        ptr = perm_dev.data_ptr() if perm_dev is not None else None
+        check(self.lib.cae_dp_train_steps(self.handle, which, ptr, int(batch), int(global_batch), 1 if sync_bn else 0,
+                                          int(nsteps)))
+        self._advance(int(global_batch) * int(nsteps), nsteps)
+        self.num_batches_tracked += nsteps
+        self.adam_steps += nsteps
+
+    def dp_eval_steps(self, which, perm_dev, batch, global_batch, nsteps=1):
+        ptr = perm_dev.data_ptr() if perm_dev is not None else None
+        check(self.lib.cae_dp_eval_steps(self.handle, which, ptr, int(batch), int(global_batch), int(nsteps)))
+        self._advance(int(global_batch) * int(nsteps), nsteps)
+
+    def dp_read_losses(self, first, n):
+        out = (C.c_double * n)()
+        check(self.lib.cae_dp_read_losses(self.handle, first, n, out))
+        return [float(v) for v in out]
+
     def score(self, x):
         """eval-mode forward of an explicit batch (B,C,H,W) fp32 CUDA tensor -> (B,C,H,W)"""
         if x.dtype != torch.float32 or not x.is_cuda:

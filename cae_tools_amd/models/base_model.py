@@ -62,6 +62,26 @@ class BaseModel:
         """eval-mode forward of an (N,C,H,W) fp32 CUDA tensor; implemented by the sub-class"""
         raise NotImplementedError
 
+    def _score_all(self, x):
+        """_score_device over the whole array; under a torch.distributed.run launch the cases are sharded over the
+        ranks (no exchange while scoring: SURVEY.md §8e) and the scores all-gathered, so every rank returns all of
+        them.  Collective: every rank must call it with the same number of cases."""
+        from .. import dp as _dp
+        dist = _dp.ensure_process_group()
+        n = int(x.shape[0])
+        if dist is None or n < dist.get_world_size():
+            return self._score_device(x)
+        (world, rank) = (dist.get_world_size(), dist.get_rank())
+        (lo, hi) = _dp.shard_bounds(n, world, rank)
+        mine = self._score_device(x[lo:hi])
+        per = -(-n // world)
+        pad = torch.zeros((per,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+        pad[:hi - lo] = mine
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        sizes = [b - a for (a, b) in (_dp.shard_bounds(n, world, r) for r in range(world))]
+        return torch.cat([p[:k] for p, k in zip(parts, sizes)])
+
     def evaluate(self, dataset, device=None):
         """score every case, denormalise, and pool the reference's metrics (:69-100).  Scores, truth and mask
         stay on the GPU; cae_metric_sums reduces each case to eight fp64 sums.  The mask is all ones unless the
@@ -69,7 +89,7 @@ class BaseModel:
         INPUT's shape, which cannot index the output; the intended all-pixels mask is used - SURVEY.md headline 3)."""
         dataset.set_normalise_output(False)
         truth = dataset.device_outputs()
-        scores = self._score_device(dataset.device_inputs())
+        scores = self._score_all(dataset.device_inputs())
         mm = DeviceModelMetric()
         mm.accumulate(truth, scores, dataset.device_mask(), dataset.min_output, dataset.max_output)
         return mm.get_metrics()
@@ -84,7 +104,7 @@ class BaseModel:
         ds = DSDataset(score_ds, input_variables, input_variables[0], normalise_in=self.normalise_input,
                        mask_variable_name=mask_variable_name)
         ds.set_normalisation_parameters(self.normalisation_parameters)
-        y = self._score_device(ds.device_inputs())
+        y = self._score_all(ds.device_inputs())     # cases sharded over the GPUs of a torch.distributed.run launch
         out = ds.denormalise_device(y)   # fp64 on the device: min + y*(max-min), then one D2H copy
         score_ds[prediction_variable] = _make_data_array(score_ds, out.cpu().numpy(),
                                                          (n_dimension, channel_dimension, y_dimension, x_dimension))

@@ -17,6 +17,7 @@ import time
 import numpy as np
 import torch
 
+from .. import dp as _dp
 from .. import engine as _eng
 from .base_model import BaseModel
 from .model_sizer import create_model_spec, ModelSpec
@@ -63,6 +64,10 @@ class ConvAEModel(BaseModel):
         self.optim = None
         self.db = ModelDatabase(database_path) if database_path else None   # conv_ae_model.py:75
         self._engine = None
+        # build-only: behaviour under a torch.distributed.run launch (one process per GPU).  batch_size stays the GLOBAL
+        # batch; sync_bn=True computes BatchNorm statistics over it (N ranks reproduce the single-device step, the
+        # reference's semantics), False keeps per-rank statistics (throughput mode)
+        self.sync_bn = True
 
     # ---- persistence ---------------------------------------------------------------------
     def get_parameters(self):
@@ -150,7 +155,8 @@ class ConvAEModel(BaseModel):
         return self._engine
 
     def _score_device(self, x):
-        eng = self._get_engine(max(1, min(int(self.batch_size), int(x.shape[0]))))
+        # an engine that exists is used as it is (score() walks the array in chunks of its max_batch)
+        eng = self._engine if self._engine is not None else self._get_engine(max(1, min(int(self.batch_size), int(x.shape[0]))))
         return eng.score(x)
 
     def score(self, batches, save_arr):
@@ -197,43 +203,71 @@ class ConvAEModel(BaseModel):
         train_perm = _index_batches(len(train_ds), self.batch_size)
         test_perm = _index_batches(len(test_ds), self.batch_size)
 
-        print(f"Running on device: {torch.device('cuda')}")
+        # Data parallel (build-only; the reference selects ONE device at :294-297 and moves the modules there at :312-313):
+        # under a torch.distributed.run launch every rank holds the model and both data sets, takes its rows of each frozen
+        # GLOBAL batch (dp.shard_bounds) and the gradients are all-reduced inside libcae_hip; rank 0 prints and saves.
+        dist = _dp.ensure_process_group()
+        (world, rank) = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
+        lead = rank == 0
+        if dist is not None:    # one frozen shuffle for everybody: rank 0's draw
+            box = [train_perm, test_perm]
+            dist.broadcast_object_list(box, src=0)
+            (train_perm, test_perm) = box
+
+        if lead:
+            print(f"Running on device: {torch.device('cuda')}")
         start = time.time()
 
-        eng = self._get_engine(int(self.batch_size))
+        eng = self._get_engine(-(-int(self.batch_size) // world))   # a rank's share of a global batch
         eng.set_hyper(lr=self.lr, weight_decay=self.weight_decay)
         eng.reset_optimizer()      # torch.optim.Adam is re-created on every train() (:310)
         eng.set_dataset(_eng.TRAIN, train_ds.device_inputs(), train_ds.device_outputs())
         eng.set_dataset(_eng.TEST, test_ds.device_inputs(), test_ds.device_outputs())
         train_idx = eng.upload_perm(train_perm)
         test_idx = eng.upload_perm(test_perm)
+        par = None
+        if dist is not None:
+            par = _dp.DataParallel(eng, dist, sync_bn=self.sync_bn)
+            par.broadcast_parameters(0)     # rank 0's initial (or loaded) weights and running statistics everywhere
+
+        def one_pass(which, idx, n, train):
+            if par is None:
+                return eng.run_batches(which, idx, n, self.batch_size, train=train)
+            if not train:
+                par.broadcast_buffers(0)    # every rank scores with the same running statistics
+            return par.run_batches(which, idx, n, self.batch_size, train=train)
 
         train_loss = test_loss = 0.0
         for epoch in range(self.nr_epochs):
-            train_loss = float(np.mean(eng.run_batches(_eng.TRAIN, train_idx, len(train_ds), self.batch_size, train=True)))
+            train_loss = float(np.mean(one_pass(_eng.TRAIN, train_idx, len(train_ds), True)))
             if epoch % self.test_interval == 0:
-                test_loss = float(np.mean(eng.run_batches(_eng.TEST, test_idx, len(test_ds), self.batch_size, train=False)))
+                test_loss = float(np.mean(one_pass(_eng.TEST, test_idx, len(test_ds), False)))
                 self.history["train_loss"].append(train_loss)
                 self.history["test_loss"].append(test_loss)
-                print("%5d %.6f %.6f" % (epoch, train_loss, test_loss))
+                if lead:
+                    print("%5d %.6f %.6f" % (epoch, train_loss, test_loss))
+        if par is not None:
+            par.broadcast_buffers(0)
 
         elapsed = time.time() - start
         self.history["nr_epochs"] = self.history["nr_epochs"] + self.nr_epochs
-        print("elapsed:" + str(elapsed))
+        if lead:
+            print("elapsed:" + str(elapsed))
 
-        if self.db:     # :343-345
+        if self.db and lead:     # :343-345
             self.db.add_training_result(self.get_model_id(), "ConvAE", output_variable, input_variables, self.summary(),
                                         model_path, training_paths, train_loss, testing_paths, test_loss,
                                         self.get_parameters(), self.spec.save())
-        if model_path:
+        if model_path and lead:
             self.save(model_path)
         else:
             self._pull_weights()
 
         metrics = {"test": self.evaluate(test_ds), "train": self.evaluate(train_ds)}
-        self.dump_metrics("Test Metrics", metrics["test"])
-        self.dump_metrics("Train Metrics", metrics["train"])
-        if self.db:     # :358-359
+        if lead:
+            self.dump_metrics("Test Metrics", metrics["test"])
+            self.dump_metrics("Train Metrics", metrics["train"])
+        if self.db and lead:     # :358-359
             self.db.add_evaluation_result(self.get_model_id(), training_paths, testing_paths, metrics)
         return metrics
 

@@ -146,6 +146,42 @@ typedef int (*cae_allreduce_fn)(void* user, void* table_dev, int64_t count_doubl
 int cae_forward_backward_sync(cae_engine* e, int which, const int32_t* perm_dev, int batch, int global_batch,
                               int world, cae_allreduce_fn fn, void* user);
 
+/* ---- data parallelism inside the library ---------------------------------------------------------
+ * The reference trains on ONE device (device selection conv_ae_model.py:294-297, modules moved at :312-313); sharding a
+ * step over the GPUs of a node is this build's addition.  One process per GPU, each with its own engine
+ * holding the whole (replicated) model and data set; rank r takes rows [lo, hi) of every frozen global batch.  The library
+ * owns an RCCL communicator (bound at run time from the librccl.so already resident in the process, else the library
+ * path's) and a second HIP stream.  A data-parallel step = forward + backward of the local shard with the loss scaled by
+ * 1/global count; the fp64 gradient accumulators are narrowed to fp32 and all-reduced (SUM) in two buckets in the order
+ * backward completes them - Linear 3 + decoder convolutions on the second stream while Linear 2..0 and the encoder
+ * backward still run, then the rest - and Adam runs from the reduced gradients: weights stay bit-identical on all ranks.
+ * The whole step, collectives included, is replayed from one hipGraph when cae_dp_init's self-test could capture RCCL
+ * calls (else plain launches: same kernels, same results).
+ *
+ * cae_dp_unique_id: rank 0 obtains the 128-byte rendezvous id; the host hands the same bytes to every rank (any
+ *   channel: torch.distributed broadcast, MPI, a file).
+ * cae_dp_init: collective over all ranks; the calling thread's current HIP device is this rank's GPU.  Runs a self-test
+ *   (all-reduce of ones, plain and captured).  cae_bind and cae_set_stream (non-NULL stream) must have been called.
+ * cae_dp_broadcast_state: what = 1 parameters | 2 BatchNorm running statistics | 4 Adam moments, from rank `root` (blocking).
+ * cae_dp_train_step(s): batch = this rank's shard size (0 allowed: the rank only takes part in the collectives),
+ *   global_batch = sum over ranks; the device cursor advances by global_batch per step, so the host points it at
+ *   global_start + lo once and nsteps consecutive global batches run from one graph.  sync_bn = 1: BatchNorm statistics
+ *   over the GLOBAL batch - every sum table ([8][C][4] fp64) is all-reduced in-stream right after the launch that completes
+ *   it (2 per BatchNorm layer per step), which makes N ranks x batch/N reproduce the reference's single-device batch-N
+ *   step (encoder.py:45, decoder.py:47 normalise over the whole batch); sync_bn = 0: per-rank statistics (what torch's
+ *   DistributedDataParallel does without SyncBatchNorm), for throughput.
+ * cae_dp_eval_steps: __test_epoch on this rank's shard of each global test batch (loss scaled by 1/global count).
+ * cae_dp_read_losses: cae_read_losses of the SUM over ranks = the global-batch means (collective, blocking). */
+int cae_dp_unique_id(void* id128_host);
+int cae_dp_init(cae_engine* e, int world, int rank, const void* id128_host);
+int cae_dp_shutdown(cae_engine* e);
+int cae_dp_info(const cae_engine* e, int* world, int* rank, int* graph_capture);
+int cae_dp_broadcast_state(cae_engine* e, int root, int what);
+int cae_dp_train_step(cae_engine* e, int which, const int32_t* perm_dev, int batch, int global_batch, int sync_bn);
+int cae_dp_train_steps(cae_engine* e, int which, const int32_t* perm_dev, int batch, int global_batch, int sync_bn, int nsteps);
+int cae_dp_eval_steps(cae_engine* e, int which, const int32_t* perm_dev, int batch, int global_batch, int nsteps);
+int cae_dp_read_losses(cae_engine* e, int first, int count, double* host_out);
+
 /* One iteration of __test_epoch (conv_ae_model.py:205-221): eval-mode forward + MSE into the
  * loss slot; nothing else is written. */
 int cae_eval_step(cae_engine* e, int which, const int32_t* perm_dev, int batch);
