@@ -167,6 +167,7 @@ def main():
     global_batch = BATCH * world
     steps_per_epoch = N_TRAIN // global_batch
     dp_graph = None
+    dp_times = {}
 
     if dist is None:
         def run(nsteps):
@@ -181,6 +182,8 @@ def main():
         dp.broadcast_parameters(0)
         dp_graph = eng.dp_graph_capture()
         (lo, hi) = shard_bounds(global_batch, world, rank)
+        # the two launch structures of the exchange, timed on the live communicator; the faster is kept (untimed region)
+        dp_times = eng.dp_calibrate(dist, 0, perm, lo, hi - lo, global_batch, args.sync_bn)
 
         def run(nsteps):
             done = 0
@@ -224,8 +227,12 @@ def main():
                        "global_batch": BATCH * world, "n_train": N_TRAIN, "params": 112271,
                        "parallelism": (f"dp{world}" + ("+syncbn" if args.sync_bn else "")) if dist is not None else "single",
                        "dp_collectives": None if dist is None else
-                       ("RCCL all-reduce of 2 gradient buckets on a second stream, " +
-                        ("captured in the step graph" if dp_graph else "plain launches"))},
+                       ("RCCL all-reduce of 2 gradient buckets, " +
+                        ("first one on a second stream beside the tail of backward" if eng.dp_overlap and not args.sync_bn
+                         else "both on the main stream after backward") +
+                        (", captured in the step graph" if dp_graph else ", plain launches")),
+                       "dp_calibration_us_per_step": None if dist is None else
+                       {k: round(v * 1e6, 1) for k, v in dp_times.items()}},
             "step_roofline": {"algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE,
                               "achieved_GBs": value / world * ALGO_BYTES_PER_IMAGE / 1e9,
                               "frac_of_8TBs": value / world * ALGO_BYTES_PER_IMAGE / 1e9 / HBM_PEAK_GBS},

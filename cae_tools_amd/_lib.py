@@ -59,6 +59,7 @@ SIGNATURES = {
     "cae_dp_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "cae_dp_shutdown": (C.c_int, [_P]),
     "cae_dp_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "cae_dp_set_overlap": (C.c_int, [_P, C.c_int]),
     "cae_dp_broadcast_state": (C.c_int, [_P, C.c_int, C.c_int]),
     "cae_dp_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "cae_dp_train_steps": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -121,6 +121,7 @@ struct cae_engine {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool dp_graph_ok = true;            // RCCL calls captured inside the step graph (checked by cae_dp_init's self-test)
+    bool dp_overlap = true;             // first gradient bucket on the second stream (cae_dp_set_overlap)
     std::vector<int> sync_order;        // BatchNorm tables in the order a SyncBN step all-reduces them
     size_t sync_pos = 0;
     int64_t bucket_split = 0;           // gradient buckets: [bucket_split, n_param) first (decoder), [0, bucket_split) last
@@ -640,9 +641,9 @@ bool tail_plan(const cae_engine* e, const StepArgs& a, TailArgs& t, size_t& lds_
 // ---- data-parallel gradient exchange (cae_dp_train_step) -------------------------------------------
 // Two buckets in the order backward completes them: [bucket_split, n_param) = Linear 3 and the decoder convolutions, ready
 // as soon as Linear 3's backward has run, narrowed to fp32 and all-reduced on the second stream while the main stream
-// still runs Linear 2..0 and the encoder backward; then [0, bucket_split).  Both on ONE communicator used from ONE stream.
-// Under SyncBN every collective (tables and buckets) stays on the main stream instead: the tables are on the critical
-// path anyway, and one communicator is never driven from two streams at once.
+// still runs Linear 2..0 and the encoder backward; then [0, bucket_split) on the main stream once the first has finished
+// (one communicator, one collective at a time, ordered on the device by the join event).
+// Under SyncBN every collective (tables and buckets) stays on the main stream: the tables are on the critical path anyway.
 StepTail narrow_tail(cae_engine* e, bool with_step_tail, int batch_inc) {
     StepTail t = step_tail_of(e, batch_inc, 1);
     if (!with_step_tail) {
@@ -659,11 +660,18 @@ int dp_allreduce_grads(cae_engine* e, int64_t lo, int64_t hi, hipStream_t on) {
     return CAE_OK;
 }
 
+// first bucket on the second stream (cae_dp_set_overlap; the env variable, read once, overrides it for measurements)
+bool dp_overlap(const cae_engine* e, const StepArgs& a) {
+    static const int forced = env_int("CAE_DP_OVERLAP", -1);
+    return (forced >= 0 ? forced != 0 : e->dp_overlap) && !a.dp_sync;
+}
+
 int dp_first_bucket(cae_engine* e, const StepArgs& a) {
     if (!a.dp) return CAE_OK;
     const int64_t lo = e->bucket_split, hi = e->n_param;
-    hipStream_t on = a.dp_sync ? e->stream : e->comm_stream;
-    if (!a.dp_sync) {
+    const bool overlap = dp_overlap(e, a);
+    hipStream_t on = overlap ? e->comm_stream : e->stream;
+    if (overlap) {
         HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
         HIP_TRY(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
     }
@@ -672,7 +680,9 @@ int dp_first_bucket(cae_engine* e, const StepArgs& a) {
         hipLaunchKernelGGL(k_narrow_range, dim3(grid1(hi - lo)), dim3(256), 0, on, (long long)lo, (long long)hi, e->grads,
                            e->shard_segs(), narrow_tail(e, false, 0));
     }
-    return dp_allreduce_grads(e, lo, hi, on);
+    if (int rc = dp_allreduce_grads(e, lo, hi, on)) return rc;
+    if (overlap) HIP_TRY(hipEventRecord(e->ev_join, e->comm_stream));
+    return CAE_OK;
 }
 
 // after the last backward kernel: second bucket, join, Adam from the reduced fp32 gradients
@@ -684,15 +694,11 @@ int dp_finish_step(cae_engine* e, const StepArgs& a) {
         hipLaunchKernelGGL(k_narrow_range, dim3(grid1(hi - lo > 0 ? hi - lo : 1)), dim3(256), 0, s, (long long)lo, (long long)hi,
                            e->grads, e->shard_segs(), narrow_tail(e, true, a.inc()));
     }
-    if (a.dp_sync) {
-        if (int rc = dp_allreduce_grads(e, lo, hi, s)) return rc;
-    } else {
-        HIP_TRY(hipEventRecord(e->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
-        if (int rc = dp_allreduce_grads(e, lo, hi, e->comm_stream)) return rc;
-        HIP_TRY(hipEventRecord(e->ev_join, e->comm_stream));
-        HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
-    }
+    // the first bucket's all-reduce has to be over before the second is enqueued: one communicator runs one collective at a
+    // time, and the join orders the two on the device (one fork + one join per step; the second bucket is last on the
+    // critical path either way, so it runs on the main stream)
+    if (dp_overlap(e, a)) HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
+    if (int rc = dp_allreduce_grads(e, lo, hi, s)) return rc;
     StepTail none;
     memset(&none, 0, sizeof none);
     ProfScope _p(e, "adam", 0, 28.0 * e->n_param);
@@ -1720,9 +1726,9 @@ int dp_self_test(cae_engine* e) {
         HIP_TRY(hipEventRecord(e->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
         if (int rc = dp_allreduce_grads(e, mid, n, e->comm_stream)) return rc;
-        if (int rc = dp_allreduce_grads(e, 0, mid, e->comm_stream)) return rc;
         HIP_TRY(hipEventRecord(e->ev_join, e->comm_stream));
         HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
+        if (int rc = dp_allreduce_grads(e, 0, mid, s)) return rc;
         return CAE_OK;
     };
     auto fill = [&]() {
@@ -1803,6 +1809,13 @@ int cae_dp_info(const cae_engine* e, int* world, int* rank, int* graph_capture) 
     if (world) *world = e->dp_world;
     if (rank) *rank = e->dp_rank;
     if (graph_capture) *graph_capture = e->dp_comm && e->dp_graph_ok && e->graph_mode ? 1 : 0;
+    return CAE_OK;
+}
+
+int cae_dp_set_overlap(cae_engine* e, int enabled) {
+    if (!e) return fail(CAE_ERR_ARG, "null engine");
+    if (e->dp_overlap != (enabled != 0)) e->drop_graphs();
+    e->dp_overlap = enabled != 0;
     return CAE_OK;
 }
 

@@ -34,7 +34,7 @@ def shard_bounds(n, world, rank):
 
 class DataParallel:
 
-    def __init__(self, engine, dist, group=None, sync_bn=False):
+    def __init__(self, engine, dist, group=None, sync_bn=False, overlap="auto"):
         self.engine = engine
         self.dist = dist
         self.group = group
@@ -44,6 +44,17 @@ class DataParallel:
         self.native = hasattr(engine, "dp_train_steps")
         if self.native and getattr(engine, "dp_world", 0) != self.world:
             engine.dp_init(dist, group)
+        # native engines: first gradient bucket on the second stream (True), both on the main stream (False), or whichever
+        # HipEngine.dp_calibrate measures as faster on this communicator, decided once before the first training step
+        self.overlap = overlap
+        self.calibration = None
+        if self.native and overlap != "auto":
+            engine.dp_set_overlap(bool(overlap))
+
+    def _calibrate(self, which, perm, start, batch, global_batch):
+        if self.native and self.overlap == "auto" and self.calibration is None and not self.sync_bn and batch > 0:
+            self.calibration = self.engine.dp_calibrate(self.dist, which, perm, start, batch, global_batch, False,
+                                                        group=self.group)
 
     def _stream_ctx(self):
         stream = getattr(self.engine, "stream", None)
@@ -86,6 +97,7 @@ class DataParallel:
         gb = global_batch if global_batch is not None else size * self.world
         eng = self.engine
         if self.native:
+            self._calibrate(which, perm, start, size, gb)
             slot = eng.claim_slots(1)
             eng.set_cursor(start, slot)
             eng.dp_train_steps(which, perm, size, gb, self.sync_bn, 1)
@@ -121,6 +133,8 @@ class DataParallel:
 
         if full:
             (lo, hi) = shard_bounds(global_batch, self.world, self.rank)
+            if train:
+                self._calibrate(which, perm, lo, hi - lo, global_batch)
             eng.set_cursor(lo, first)      # the device cursor then moves one global batch per step
             left = full
             per_graph = getattr(eng, "STEPS_PER_GRAPH", 64)

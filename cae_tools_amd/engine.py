@@ -380,6 +380,53 @@ class HipEngine(EnginePlan):
         what = (1 if params else 0) | (2 if buffers else 0) | (4 if moments else 0)
         check(self.lib.cae_dp_broadcast_state(self.handle, int(root), what))
 
+    def dp_set_overlap(self, enabled):
+        check(self.lib.cae_dp_set_overlap(self.handle, 1 if enabled else 0))
+        self.dp_overlap = bool(enabled)
+
+    dp_overlap = True
+
+    def dp_calibrate(self, dist, which, perm_dev, start, batch, global_batch, sync_bn, group=None, steps=48, warm=8):
+        """Choose between the two launch structures of a data-parallel step - first gradient bucket all-reduced on the
+        second stream beside the tail of backward, or both buckets on the main stream after it - by timing `steps` real
+        steps of each on the live communicator, then putting every piece of training state back.  The arithmetic is the
+        same either way; a fork/join between two hardware queues costs ~20 us in a replayed graph on this stack, which the
+        overlap only earns back when the first bucket's all-reduce is slower than that.  Collective: every rank calls it
+        with the same arguments; the slowest rank's times decide, so all ranks agree.  Returns {mode: seconds per step}."""
+        import time
+        if sync_bn:
+            return {}   # SyncBN keeps every collective on the main stream
+        self.sync()
+        keep = [t.clone() for t in (self.params, self.buffers, self.exp_avg, self.exp_avg_sq, self.grads)]
+        counters = (self.num_batches_tracked, self.adam_steps, self._slot)
+        slot = self._claim_slots(1)
+        times = {}
+        for mode in (True, False):
+            self.dp_set_overlap(mode)
+            for (n, timed) in ((warm, False), (steps, True)):
+                self.sync()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    self._set_cursor(start, slot)       # the same batch and loss slot every time
+                    self.dp_train_steps(which, perm_dev, batch, global_batch, False, 1)
+                self.sync()
+                if timed:
+                    times[mode] = (time.perf_counter() - t0) / n
+        t = torch.tensor([times[True], times[False]], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        (with_overlap, without) = (float(t[0]), float(t[1]))
+        self.dp_set_overlap(with_overlap < without)
+        # restore: parameters, running statistics, Adam moments and step count, host counters; drain the loss slot
+        self.sync()
+        for (dst, src) in zip((self.params, self.buffers, self.exp_avg, self.exp_avg_sq, self.grads), keep):
+            dst.copy_(src)
+        torch.cuda.synchronize(self.device)
+        (self.num_batches_tracked, self.adam_steps, self._slot) = counters
+        check(self.lib.cae_set_adam_step(self.handle, int(self.adam_steps)))
+        self._read_losses(slot, 1)
+        self._cursor = None
+        return {"overlap": with_overlap, "serial": without}
+
     def claim_slots(self, n):
         return self._claim_slots(n)
 
