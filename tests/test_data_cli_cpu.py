@@ -66,7 +66,9 @@ def test_train_cli_flag_surface():
         for o in a.option_strings:
             if o.startswith("--") and o != "--help":
                 got[o] = a.default
-    assert got == REFERENCE_TRAIN_FLAGS
+    build_only = {"--gpus": 1, "--local-bn": False}     # data-parallel flags the reference does not have
+    assert {k: v for k, v in got.items() if k in build_only} == build_only
+    assert {k: v for k, v in got.items() if k not in build_only} == REFERENCE_TRAIN_FLAGS
     required = {o for a in p._actions if a.required for o in a.option_strings}
     assert required == {"--train-inputs", "--test-inputs", "--model-folder", "--input-variables", "--output-variable"}
     args = p.parse_args(["--train-inputs", "a", "b", "--test-inputs", "c", "--model-folder", "m", "--input-variables",
@@ -80,6 +82,41 @@ def test_apply_cli_flag_surface():
     a = p.parse_args(["in1.nc", "in2.nc", "out.nc", "--model-folder", "m"])
     assert a.data_paths == ["in1.nc", "in2.nc"] and a.output_path == "out.nc"
     assert a.prediction_variable == "model_output" and a.input_variables is None and a.mask_variable is None
+    assert a.gpus == 1
+
+
+def test_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
+    """--gpus N re-runs the command under torch.distributed.run as a CHILD process (this process never touches the GPU),
+    with the rendezvous on 127.0.0.1; inside a rank it is a no-op, and only rank 0 keeps its stdout"""
+    import sys
+    from cae_tools_amd.cli import _launch
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"] = cmd
+        seen["env"] = env
+        return 7
+
+    monkeypatch.setattr(_launch.subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert _launch.maybe_spawn_ranks("cae_tools_amd.cli.train_cae", 1, ["--x"]) is None and not seen
+    assert _launch.maybe_spawn_ranks("cae_tools_amd.cli.train_cae", 4, ["--method", "conv", "--gpus", "4"]) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["-m", "cae_tools_amd.cli.train_cae", "--method", "conv", "--gpus", "4"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    seen.clear()
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "0")
+    assert _launch.maybe_spawn_ranks("cae_tools_amd.cli.train_cae", 4, []) is None and not seen
+    out = sys.stdout
+    monkeypatch.setenv("RANK", "2")
+    try:
+        assert _launch.maybe_spawn_ranks("cae_tools_amd.cli.train_cae", 4, []) is None
+        assert sys.stdout is not out
+    finally:
+        sys.stdout = out
 
 
 def test_model_metric_matches_direct_formulas():
