@@ -72,14 +72,14 @@ def _same(u, v, what, lr_steps):
 
 
 @pytest.mark.parametrize("name", ["cfg2_b4", "handspec_b4", "tidal_b3"])
-@pytest.mark.parametrize("sync_bn", [False, True])
-def test_one_rank_group_equals_the_fused_step(dist1, name, sync_bn):
+@pytest.mark.parametrize("sync_bn,overlap", [(False, True), (False, False), (True, True)])
+def test_one_rank_group_equals_the_fused_step(dist1, name, sync_bn, overlap):
     from cae_tools_amd.dp import DataParallel
     case = GoldenCase(name)
     (x, t) = _data(case)
     n = x.shape[0]
     (a, b) = (_make(case, x, t), _make(case, x, t))
-    dp = DataParallel(b, dist1, sync_bn=sync_bn, overlap=True)      # the second-stream structure
+    dp = DataParallel(b, dist1, sync_bn=sync_bn, overlap=overlap)   # True: first bucket on the second stream
     assert dp.native and b.dp_world == 1
     dp.broadcast_parameters(0)
     (la, lb) = ([], [])
@@ -106,38 +106,52 @@ def test_one_rank_group_equals_the_fused_step(dist1, name, sync_bn):
     assert b.adam_steps == a.adam_steps == 4 and b.num_batches_tracked == 4
 
 
+def test_calibration_leaves_the_training_state_alone(dist1):
+    from cae_tools_amd.dp import DataParallel
+    case = GoldenCase("cfg2_b4")
+    (x, t) = _data(case)
+    n = x.shape[0]
+    b = _make(case, x, t)
+    dp = DataParallel(b, dist1, sync_bn=False)
+    dp.train_step(0, None, 0, n)                     # calibrates first (overlap="auto"), then takes ONE step
+    assert dp.calibration and b.adam_steps == 1 and b.num_batches_tracked == 1
+    a = _make(case, x, t)
+    a.train_step(0, None, 0, n)
+    for (u, v, what) in zip(_state(a), _state(b), ("params", "buffers", "exp_avg", "exp_avg_sq")):
+        _same(u, v, what, case.meta["lr"])
+
+
 def test_passes_over_global_batches_match_the_single_device_passes(dist1):
     from cae_tools_amd.dp import DataParallel
     case = GoldenCase("cfg1_b3")
     (x, t) = _data(case)
-    reps = 70 * 2 // x.shape[0] + 1
-    x = x.repeat(reps, 1, 1, 1)[:141].contiguous() + 0.0     # 141 samples: 70 full batches of 2 (a 64-step graph + 6) + 1
-    t = t.repeat(reps, 1, 1, 1)[:141].contiguous()
-    x += 0.01 * torch.rand(x.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
-    (a, b) = (_make(case, x, t, max_batch=2), _make(case, x, t, max_batch=2))
-    dp = DataParallel(b, dist1, sync_bn=False)       # overlap="auto": times both structures, restores the state
-    perm_np = np.random.default_rng(5).permutation(141).astype(np.int32)
+    (n, gb) = (101, 8)                                       # 12 full global batches + a partial one of 5
+    reps = n // x.shape[0] + 1
+    x = x.repeat(reps, 1, 1, 1)[:n].contiguous()
+    t = t.repeat(reps, 1, 1, 1)[:n].contiguous()
+    x += 0.05 * torch.rand(x.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    t = (t + 0.05 * torch.rand(t.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))).clamp(0, 1)
+    (a, b) = (_make(case, x, t, max_batch=gb), _make(case, x, t, max_batch=gb))
+    a.STEPS_PER_GRAPH = b.STEPS_PER_GRAPH = 5                # 12 = 2 five-step graphs + 2 single steps
+    dp = DataParallel(b, dist1, sync_bn=False)               # overlap="auto": times both structures, restores the state
+    perm_np = np.random.default_rng(5).permutation(n).astype(np.int32)
     (pa, pb) = (a.upload_perm(perm_np), b.upload_perm(perm_np))
     for epoch in range(2):
-        la = a.run_batches(0, pa, 141, 2, train=True)
-        lb = dp.run_batches(0, pb, 141, 2, train=True)
-        assert len(lb) == 71
-        # batch-2 BatchNorm amplifies last-bit differences along the run: tight on the first pass, looser after it
-        if epoch == 0:
-            np.testing.assert_allclose(lb[:6], la[:6], rtol=1e-5)
-        np.testing.assert_allclose(lb, la, rtol=5e-3)
-        ea = a.run_batches(1, pa, 141, 2, train=False)
-        eb = dp.run_batches(1, pb, 141, 2, train=False)
-        np.testing.assert_allclose(eb, ea, rtol=5e-3)
+        la = a.run_batches(0, pa, n, gb, train=True)
+        lb = dp.run_batches(0, pb, n, gb, train=True)
+        assert len(lb) == 13
+        np.testing.assert_allclose(lb, la, rtol=2e-5)
+        ea = a.run_batches(1, pa, n, gb, train=False)
+        eb = dp.run_batches(1, pb, n, gb, train=False)
+        np.testing.assert_allclose(eb, ea, rtol=2e-5)
     assert set(dp.calibration) == {"overlap", "serial"} and all(0 < v < 0.1 for v in dp.calibration.values())
     for (u, v, what) in zip(_state(a), _state(b), ("params", "buffers", "exp_avg", "exp_avg_sq")):
-        # 142 steps apart the two runs have drifted by accumulated last-bit differences (free-running
-        # trajectories); what must hold is that they are the same run: a wrong shard, cursor or scale is O(lr) per step
         d = np.abs(u - v)
-        if what == "params":
-            assert np.quantile(d, 0.99) <= 0.05 * case.meta["lr"] * 142, np.quantile(d, 0.99)
+        if what == "params":       # the same run up to the arrival order of fp64 atomics (bounds as in test_hip_parity's Adam checks)
+            lr26 = case.meta["lr"] * 26
+            assert d.max() <= 0.25 * lr26 and np.quantile(d, 0.999) <= 0.02 * lr26, (d.max(), np.quantile(d, 0.999))
         elif what == "buffers":
-            assert d.max() <= 2e-2 * np.abs(u).max(), d.max()
+            assert d.max() <= 1e-4 * np.abs(u).max(), d.max()
 
 
 def test_a_shard_contributes_its_share_of_the_global_mean(dist1):
