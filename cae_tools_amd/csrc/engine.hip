@@ -18,6 +18,7 @@
 #include "kernels_s2.h"
 #include "kernels_gemm.h"
 #include "kernels_igemm.h"
+#include "kernels_ctlds.h"
 #include "kernels_head.h"
 #include "dp_comm.h"
 
@@ -355,6 +356,25 @@ void s2_fwd_launch(S2Fwd a, hipStream_t s) {
     if ((long long)a.B * px * py < 100000) {
         // small maps: 4x4 outputs per thread would leave most SIMDs without a wave; one quad per thread
         const int qx = (a.OW + 1) / 2, qy = (a.OH + 1) / 2;
+        if constexpr (CIN * COUT * KH * KW > 80 && (256 / COUT) % 64 == 0) {
+            // intermediate layers with many weights: output channels split over the waves (k_s2_fwd_cs)
+            static const int cs_on = env_int("CAE_S2_CS", 1);   // env: A/B measurements only
+            if (cs_on && (a.epi == S2_RAW_STATS || a.epi == S2_RAW)) {
+                constexpr int PIX = 256 / COUT;
+                if (qx > 32) {
+                    a.tiles_x = (qx + 63) / 64;
+                    a.tiles_y = (qy + PIX / 64 - 1) / (PIX / 64);
+                    a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+                    hipLaunchKernelGGL((k_s2_fwd_cs<CIN, COUT, KH, KW, 64>), dim3(a.total_tiles < capf ? a.total_tiles : capf), dim3(256), 0, s, a);
+                } else {
+                    a.tiles_x = (qx + 31) / 32;
+                    a.tiles_y = (qy + PIX / 32 - 1) / (PIX / 32);
+                    a.total_tiles = a.B * a.tiles_x * a.tiles_y;
+                    hipLaunchKernelGGL((k_s2_fwd_cs<CIN, COUT, KH, KW, 32>), dim3(a.total_tiles < capf ? a.total_tiles : capf), dim3(256), 0, s, a);
+                }
+                return;
+            }
+        }
         if (qx > 32) {
             a.tiles_x = (qx + 63) / 64;
             a.tiles_y = (qy + 3) / 4;
@@ -439,6 +459,62 @@ void s2_bwd_dispatch(const ConvLayer& L, const S2Bwd& a, hipStream_t s) {
     S2_SHAPES(PAIR)
 #undef PAIR
 #undef ONE
+}
+
+template <class K>
+void head_lds_attr(K kernel, size_t bytes) {
+    static size_t granted = 64 * 1024;
+    if (bytes > granted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        granted = bytes;
+    }
+}
+
+// ---- LDS-staged implicit-GEMM forward of a channel-rich stride-2 ConvTranspose2d (kernels_ctlds.h) ---------------------
+// false: the layer does not fit this kernel (odd channel counts, kernels other than 3/4 taps, an image + weight slice
+// larger than LDS); the caller then runs the gather kernel k_ig_fwd_s2.
+template <int KH, int KW>
+void ct_fwd_go(const CtFwd& c, dim3 grid, int threads, size_t lds, hipStream_t s) {
+    head_lds_attr(k_ct_fwd_lds<KH, KW>, lds);
+    hipLaunchKernelGGL((k_ct_fwd_lds<KH, KW>), grid, dim3(threads), lds, s, c);
+}
+
+bool ct_fwd_launch(cae_engine* e, const StepArgs& a, const ConvLayer& L, int layer, const float* in, const BnDesc& bn_in,
+                   float* out, double* stats) {
+    static const int enabled = env_int("CAE_CTLDS", 1);        // env: A/B measurements only
+    static const int mf_target = env_int("CAE_CT_MF", 24);     // env: tuning only - MFMAs per wave before K is split further
+    if (!enabled || L.cin % 4 || L.kh < 3 || L.kw < 3) return false;
+    CtFwd c;
+    memset(&c, 0, sizeof c);
+    c.B = a.batch; c.Cin = L.cin; c.H = L.hin; c.W = L.win; c.Cout = L.cout; c.OH = L.hout; c.OW = L.wout;
+    c.QH = (L.hout + 1) / 2; c.QW = (L.wout + 1) / 2;
+    c.PW = c.QW + 1;
+    c.plane = ((c.QH + 1) * c.PW) | 1;
+    c.tiles = (c.QH * c.QW + 15) / 16;
+    const int taps = ((L.kh + 1) / 2 + L.kh / 2) * ((L.kw + 1) / 2 + L.kw / 2);   // sum of n_p over the four parities = kh * kw
+    const int mf = L.cin * taps / 4;
+    int ks = 1;
+    while (ks < 8 && mf / ks > mf_target && L.cin % (ks * 2 * 4) == 0) ks *= 2;
+    int rt = 8 / ks;
+    if (rt > c.tiles) rt = c.tiles;
+    if (rt > 4) rt = 4;
+    c.ks = ks; c.rt = rt;
+    c.tg = (c.tiles + rt - 1) / rt;
+    const int waves = rt * ks;
+    const size_t lds = ct_fwd_lds_bytes(L.cin, c.plane, L.kh, L.kw, waves, ks);
+    if (lds > 150 * 1024 || c.plane >= kDivSmallMaxD || (long long)L.cin * c.plane >= kDivSmallMaxN) return false;
+    c.in = in; c.bn_in = bn_in; c.w = e->params + L.w_off; c.bias = e->params + L.b_off; c.out = out; c.stats = stats;
+    {
+        static const int dbg = env_int("CAE_HEAD_DBG", 0), dbg_layer = env_int("CAE_DBG_LAYER", 2);   // tools/ct_phases.py
+        c.dbg = dbg == 3 && layer == dbg_layer && a.train ? reinterpret_cast<long long*>(e->ws + e->off_scan) : nullptr;
+    }
+    dim3 grid((unsigned)(a.batch * c.tg), (unsigned)((L.cout + 15) / 16));
+    ProfScope _p(e, a.train ? "ct_convt_fwd" : "ct_convt_eval", layer, f4((double)a.batch * (L.in_elems() + L.out_elems())));
+    if (L.kh == 3 && L.kw == 3) ct_fwd_go<3, 3>(c, grid, 64 * waves, lds, e->stream);
+    else if (L.kh == 4 && L.kw == 4) ct_fwd_go<4, 4>(c, grid, 64 * waves, lds, e->stream);
+    else if (L.kh == 3 && L.kw == 4) ct_fwd_go<3, 4>(c, grid, 64 * waves, lds, e->stream);
+    else ct_fwd_go<4, 3>(c, grid, 64 * waves, lds, e->stream);
+    return true;
 }
 
 // ---- fused head / tail (kernels_head.h) ----------------------------------------------------------
@@ -563,14 +639,6 @@ bool head_plan(const cae_engine* e, const StepArgs& a, HeadArgs& h, size_t& lds_
     return lds_bytes <= 152 * 1024;
 }
 
-template <class K>
-void head_lds_attr(K kernel, size_t bytes) {
-    static size_t granted = 64 * 1024;
-    if (bytes > granted) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        granted = bytes;
-    }
-}
 
 // k_tail_bwd (kernels_head.h): Linear 2..0 backward in one launch.  False: run the per-layer pair launches.
 bool tail_plan(const cae_engine* e, const StepArgs& a, TailArgs& t, size_t& lds_bytes) {
@@ -866,6 +934,11 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             continue;
         }
         if (e->use_s2 && !last && L.stride == 2 && L.kh <= 4 && L.kw <= 4) {
+            if (ct_fwd_launch(e, a, L, (int)l, small.p, bns, ep.out, a.train ? ep.stats : nullptr)) {
+                if (a.train)
+                    if (int rc = sync_bn_table(e, a, L.bn_index)) return rc;
+                continue;
+            }
             IgFwd f;
             memset(&f, 0, sizeof f);
             f.B = B; f.Cin = L.cin; f.H = L.hin; f.W = L.win; f.Cout = L.cout; f.OH = L.hout; f.OW = L.wout;

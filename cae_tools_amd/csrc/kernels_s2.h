@@ -123,27 +123,43 @@ __global__ void __launch_bounds__(256) k_s2_fwd(S2Fwd a) {
         const float bv = a.bias[co];
         acc[co][0][0] = acc[co][0][1] = acc[co][1][0] = acc[co][1][1] = bv;
     }
-    if (active) {
-        const bool r0 = m < a.H, r1 = m >= 1 && m - 1 < a.H;   // rows m (j=0) and m-1 (j=1) exist
-        const bool c0 = n < a.W, c1 = n >= 1 && n - 1 < a.W;   // cols n (i=0) and n-1 (i=1) exist
-        const float* base = a.in + (size_t)b * CIN * a.H * a.W + (size_t)m * a.W + n;
-        // weights are wave-uniform (scalar loads); unrolling every ci would need CIN*COUT*KH*KW live
-        // scalars, so large weight sets walk ci one at a time
-#pragma unroll(CIN * COUT * KH * KW <= 80 ? CIN : 1)
+    {
+        const bool r0 = active && m < a.H, r1 = active && m >= 1 && m - 1 < a.H;   // rows m (j=0) and m-1 (j=1) exist
+        const bool c0 = n < a.W, c1 = n >= 1 && n - 1 < a.W;                       // cols n (i=0) and n-1 (i=1) exist
+        // Every load of the quad's neighbourhood - all input channels - is issued before the first use, from clamped
+        // (always valid) addresses; validity is one select after the BatchNorm transform.  A load under a predicate is a
+        // branch plus a wait at its consumer: with the channel loop not unrolled that was one memory round trip per
+        // input channel (eight for the 8->4 layer).
+        const unsigned HWu = (unsigned)(a.H * a.W);
+        const unsigned ro0 = (unsigned)min(m, a.H - 1) * a.W, ro1 = (unsigned)min(max(m - 1, 0), a.H - 1) * a.W;
+        const unsigned co0 = (unsigned)min(n, a.W - 1), co1 = (unsigned)min(max(n - 1, 0), a.W - 1);
+        const float* base = a.in + (size_t)b * CIN * HWu;
+        float vin[CIN][2][2];
+#pragma unroll
         for (int ci = 0; ci < CIN; ci++) {
-            const float* p = base + (size_t)ci * a.H * a.W;
+            const float* p = base + ci * HWu;
+            vin[ci][0][0] = p[ro0 + co0];
+            vin[ci][0][1] = p[ro0 + co1];
+            vin[ci][1][0] = p[ro1 + co0];
+            vin[ci][1][1] = p[ro1 + co1];
+        }
+        // weights are wave-uniform (scalar loads, 36 per input channel for a 4-channel 3x3 layer); the channel loop is
+        // unrolled so that the register array is indexed statically
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++) {
             float v[2][2];
-            v[0][0] = (r0 && c0) ? p[0] : 0.f;
-            v[0][1] = (r0 && c1) ? p[-1] : 0.f;
-            v[1][0] = (r1 && c0) ? p[-a.W] : 0.f;
-            v[1][1] = (r1 && c1) ? p[-a.W - 1] : 0.f;
+            v[0][0] = vin[ci][0][0]; v[0][1] = vin[ci][0][1]; v[1][0] = vin[ci][1][0]; v[1][1] = vin[ci][1][1];
             if (a.bn_in.mode != BN_NONE) {
                 const float4 k = cin4[ci];
-                v[0][0] = (r0 && c0) ? fmaxf(0.f, fmaf(v[0][0] - k.x, k.y, k.z)) : 0.f;
-                v[0][1] = (r0 && c1) ? fmaxf(0.f, fmaf(v[0][1] - k.x, k.y, k.z)) : 0.f;
-                v[1][0] = (r1 && c0) ? fmaxf(0.f, fmaf(v[1][0] - k.x, k.y, k.z)) : 0.f;
-                v[1][1] = (r1 && c1) ? fmaxf(0.f, fmaf(v[1][1] - k.x, k.y, k.z)) : 0.f;
+                v[0][0] = fmaxf(0.f, fmaf(v[0][0] - k.x, k.y, k.z));
+                v[0][1] = fmaxf(0.f, fmaf(v[0][1] - k.x, k.y, k.z));
+                v[1][0] = fmaxf(0.f, fmaf(v[1][0] - k.x, k.y, k.z));
+                v[1][1] = fmaxf(0.f, fmaf(v[1][1] - k.x, k.y, k.z));
             }
+            v[0][0] = (r0 && c0) ? v[0][0] : 0.f;
+            v[0][1] = (r0 && c1) ? v[0][1] : 0.f;
+            v[1][0] = (r1 && c0) ? v[1][0] : 0.f;
+            v[1][1] = (r1 && c1) ? v[1][1] : 0.f;
             const float* wc = a.w + (size_t)ci * COUT * KH * KW;
 #pragma unroll
             for (int co = 0; co < COUT; co++) {
@@ -252,6 +268,116 @@ __global__ void __launch_bounds__(256) k_s2_fwd(S2Fwd a) {
                 }
             }
         }
+    }
+}
+
+// ---- forward with the output channels split over the waves ----------------------------------------------------------
+// For the intermediate thin layers (8->4, 4->2; raw output + BatchNorm sums).  Wave group g of the workgroup computes
+// output channel g for the SAME quads as the other groups: a thread then needs only CIN*KH*KW wave-uniform weights (72 for
+// 8->4 at 3x3: they fit the scalar registers, where all 288 did not), keeps CIN*4 inputs + 4 accumulators in vector
+// registers (occupancy 8 instead of 1-4), and all of its loads are in flight at once.  The COUT-fold re-read of the
+// inputs is served by the CU's L1 (the inputs are the small side of these layers).
+template <int CIN, int COUT, int KH, int KW, int TW>
+__global__ void __launch_bounds__(256) k_s2_fwd_cs(S2Fwd a) {
+    constexpr int PIX = 256 / COUT;      // quads per tile
+    constexpr int TH = PIX / TW;
+    constexpr int WPG = PIX / 64;        // waves per channel group
+    static_assert(PIX % 64 == 0 && TH >= 1, "a wave must not straddle channel groups");
+    __shared__ float4 cin4[CIN];
+    __shared__ double red[4 * 2];
+    bn_consts(a.bn_in, cin4, blockIdx.x == 0);
+    __syncthreads();
+
+    const int co = __builtin_amdgcn_readfirstlane(threadIdx.x / PIX);   // wave-uniform: weights stay scalar
+    const int pix = threadIdx.x - co * PIX;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const unsigned HWu = (unsigned)(a.H * a.W);
+    const float bv = a.bias[co];
+    const bool stats = a.epi == S2_RAW_STATS;
+    double r1 = 0.0, r2 = 0.0;
+
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const int b = tile / tiles;
+        const int t = tile - b * tiles;
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        const int n = tx * TW + (pix % TW);
+        const int m = ty * TH + (pix / TW);
+        const bool active = (2 * m < a.OH) && (2 * n < a.OW);
+        const bool r0 = active && m < a.H, r1ok = active && m >= 1 && m - 1 < a.H;
+        const bool c0 = n < a.W, c1 = n >= 1 && n - 1 < a.W;
+        const unsigned ro0 = (unsigned)min(m, a.H - 1) * a.W, ro1 = (unsigned)min(max(m - 1, 0), a.H - 1) * a.W;
+        const unsigned co0 = (unsigned)min(n, a.W - 1), co1 = (unsigned)min(max(n - 1, 0), a.W - 1);
+        const float* base = a.in + (size_t)b * CIN * HWu;
+        float vin[CIN][2][2];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++) {      // clamped, unconditional: every load in flight before the first use
+            const float* p = base + ci * HWu;
+            vin[ci][0][0] = p[ro0 + co0];
+            vin[ci][0][1] = p[ro0 + co1];
+            vin[ci][1][0] = p[ro1 + co0];
+            vin[ci][1][1] = p[ro1 + co1];
+        }
+        float acc[2][2] = {{bv, bv}, {bv, bv}};
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++) {
+            float v[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    float x = vin[ci][j][i];
+                    if (a.bn_in.mode != BN_NONE) {
+                        const float4 k = cin4[ci];
+                        x = fmaxf(0.f, fmaf(x - k.x, k.y, k.z));
+                    }
+                    v[j][i] = ((j ? r1ok : r0) && (i ? c1 : c0)) ? x : 0.f;
+                }
+            const float* wc = a.w + ((size_t)ci * COUT + co) * KH * KW;
+#pragma unroll
+            for (int py = 0; py < 2; py++)
+#pragma unroll
+                for (int px = 0; px < 2; px++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int i = 0; i < 2; i++)
+                            if (py + 2 * j < KH && px + 2 * i < KW)
+                                acc[py][px] = fmaf(v[j][i], wc[(py + 2 * j) * KW + px + 2 * i], acc[py][px]);
+        }
+        if (active) {
+            const int oy = 2 * m, ox = 2 * n;
+            const bool row1 = oy + 1 < a.OH, col1 = ox + 1 < a.OW;
+            float* o = a.out + ((size_t)(b * COUT + co) * a.OH + oy) * a.OW + ox;
+            store_pair(o, acc[0][0], acc[0][1], col1);
+            if (row1) store_pair(o + a.OW, acc[1][0], acc[1][1], col1);
+            if (stats) {
+                float s1 = acc[0][0], s2 = acc[0][0] * acc[0][0];
+                if (col1) { s1 += acc[0][1]; s2 = fmaf(acc[0][1], acc[0][1], s2); }
+                if (row1) {
+                    s1 += acc[1][0]; s2 = fmaf(acc[1][0], acc[1][0], s2);
+                    if (col1) { s1 += acc[1][1]; s2 = fmaf(acc[1][1], acc[1][1], s2); }
+                }
+                r1 += (double)s1;
+                r2 += (double)s2;
+            }
+        }
+    }
+    if (!stats) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    {
+        const double t1 = wave_sum_lane63(r1), t2 = wave_sum_lane63(r2);
+        if (lane == 63) {
+            red[wv * 2] = t1;
+            red[wv * 2 + 1] = t2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * COUT) {
+        const int c = threadIdx.x >> 1, i = threadIdx.x & 1;
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < WPG; w++) sum += red[(c * WPG + w) * 2 + i];
+        atomicAdd(&a.stats[((size_t)(blockIdx.x & (kStatShards - 1)) * COUT + c) * 4 + i], sum);
     }
 }
 
@@ -450,8 +576,10 @@ __global__ void __launch_bounds__(256) k_s2_bwd(S2Bwd a) {
 // =================================================================================================
 
 __device__ __forceinline__ float sigmoid_fast(float x) {
-    // 1 / (1 + e^-x); v_rcp_f32 is good to 1 ulp, ample for a [0,1] output compared at 1e-5
-    return __builtin_amdgcn_rcpf(1.0f + expf(-x));
+    // 1 / (1 + 2^(-x log2 e)): v_exp_f32 and v_rcp_f32 are good to 1 ulp and the product's rounding error scales with |x|
+    // (~1e-7 |x| relative on e^-x), ample for a [0,1] output compared at 1e-5; saturates cleanly (2^-inf = 0, 1/inf = 0).
+    // The library expf costs ~15 instructions of range reduction per call, 16 calls per thread in the last layer.
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 
 template <int CIN, int COUT, int KH, int KW, int TWL>
