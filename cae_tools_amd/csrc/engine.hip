@@ -16,6 +16,7 @@
 #include "cae_hip.h"
 #include "kernels_generic.h"
 #include "kernels_s2.h"
+#include "kernels_last.h"
 #include "kernels_gemm.h"
 #include "kernels_igemm.h"
 #include "kernels_ctlds.h"
@@ -455,6 +456,46 @@ void s2_bwd_launch(S2Bwd a, hipStream_t s) {
 void s2_bwd_dispatch(const ConvLayer& L, const S2Bwd& a, hipStream_t s) {
 #define ONE(CI, CO, KH_, KW_) \
     if (L.cin == CI && L.cout == CO && L.kh == KH_ && L.kw == KW_) return s2_bwd_launch<CI, CO, KH_, KW_>(a, s);
+#define PAIR(CI, CO) S2_KERNELS(ONE, CI, CO)
+    S2_SHAPES(PAIR)
+#undef PAIR
+#undef ONE
+}
+
+// ---- last decoder layer of a training step as one launch (kernels_last.h): forward + sigmoid + MSE + backward ---------
+bool last_fused_ok(const cae_engine* e, const ConvLayer& L) {
+    static const int enabled = env_int("CAE_LAST_FUSED", 1);   // env: A/B measurements only
+    return enabled && s2_eligible(e, L) && L.cin * L.cout * L.kh * L.kw <= 72 && L.sh_b >= 0;
+}
+
+template <int CIN, int COUT, int KH, int KW, int HB>
+void last_fused_go(const S2Last& a, hipStream_t s) {
+    const dim3 grid((a.total + 3) / 4);
+    if (a.strips == 1 && (a.OW & 3) == 0) hipLaunchKernelGGL((k_s2_last_fused<CIN, COUT, KH, KW, HB, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_s2_last_fused<CIN, COUT, KH, KW, HB, false>), grid, dim3(256), 0, s, a);
+}
+
+template <int CIN, int COUT, int KH, int KW>
+void last_fused_launch(S2Last a, hipStream_t s) {
+    if constexpr (CIN * COUT * KH * KW <= 72) {
+        static const int hb_env = env_int("CAE_LAST_HB", 0);   // env: tuning only
+        a.QH = (a.OH + 1) / 2;
+        a.QW = (a.OW + 1) / 2;
+        const int wmax = a.W > a.QW - 1 ? a.W : a.QW - 1, hmax = a.H > a.QH - 1 ? a.H : a.QH - 1;
+        a.strips = (wmax + kLastStripPx - 1) / kLastStripPx;
+        // a wave walks a band of HB quad rows (+1 recomputed): taller bands recompute less, shorter ones give more waves
+        int hb = hb_env ? hb_env : ((long long)a.B * a.strips * ((hmax + 7) / 8) >= 1024 ? 8 : 4);
+        if (hb != 8) hb = 4;
+        a.bands = (hmax + hb - 1) / hb;
+        a.total = a.B * a.strips * a.bands;
+        if (hb == 8) last_fused_go<CIN, COUT, KH, KW, 8>(a, s);
+        else last_fused_go<CIN, COUT, KH, KW, 4>(a, s);
+    }
+}
+
+void last_fused_dispatch(const ConvLayer& L, const S2Last& a, hipStream_t s) {
+#define ONE(CI, CO, KH_, KW_) \
+    if (L.cin == CI && L.cout == CO && L.kh == KH_ && L.kw == KW_) return last_fused_launch<CI, CO, KH_, KW_>(a, s);
 #define PAIR(CI, CO) S2_KERNELS(ONE, CI, CO)
     S2_SHAPES(PAIR)
 #undef PAIR
@@ -902,6 +943,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
                 ep.target = a.want_loss ? e->ds_t[a.which] : nullptr;
             }
         }
+        if (last && a.train && last_fused_ok(e, L)) continue;   // forward, loss and backward of this layer: one launch, in launch_backward
         if (s2_eligible(e, L)) {
             S2Fwd f;
             memset(&f, 0, sizeof f);
@@ -1007,6 +1049,39 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             const ConvLayer& P = e->dec[l - 1];
             ain = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
             bna = bn_of(e, P, BN_SAVED, 0, 0);
+        }
+        if (last && last_fused_ok(e, L)) {
+            S2Last f;
+            memset(&f, 0, sizeof f);
+            f.B = B; f.H = L.hin; f.W = L.win; f.OH = L.hout; f.OW = L.wout;
+            f.in = ain.p;
+            f.w = e->params + L.w_off;
+            f.bias = e->params + L.b_off;
+            f.target = e->ds_t[a.which];
+            f.perm = a.perm;
+            f.use_cursor = a.use_cursor ? 1 : 0;
+            f.st = st;
+            f.losses = e->losses();
+            // mean over the GLOBAL batch (see launch_forward)
+            f.inv_count = (float)(1.0 / ((double)a.global_batch * L.cout * L.hout * L.wout));
+            f.bias_acc = e->sgacc() + L.sh_b;
+            f.wacc = e->sgacc() + L.sh_w;
+            f.acc_stride = e->segs.n;
+            if (l == 0) {
+                f.bn_in = bn_none();
+                f.gin = e->fptr(e->fc[3].grad_off);
+            } else {
+                const ConvLayer& P = e->dec[l - 1];
+                // this launch is also the forward consumer of the producer's BatchNorm: batch statistics, saved for the layers behind
+                f.bn_in = bn_of(e, P, BN_BATCH, (double)a.bn_batch * P.hout * P.wout, 1);
+                f.gin = e->fptr(P.grad_off);
+                f.stats_in = e->bn_stats(P.bn_index);
+            }
+            ProfScope _p(e, "s2_convt_last_fused", l, f4((double)B * (L.in_elems() * 2.0 + L.out_elems())));
+            last_fused_dispatch(L, f, s);
+            if (l > 0)
+                if (int rc = sync_bn_table(e, a, e->dec[l - 1].bn_index)) return rc;
+            continue;
         }
         if (s2_eligible(e, L)) {
             S2Bwd f;
