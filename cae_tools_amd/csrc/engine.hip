@@ -471,8 +471,10 @@ bool last_fused_ok(const cae_engine* e, const ConvLayer& L) {
 template <int CIN, int COUT, int KH, int KW, int HB>
 void last_fused_go(const S2Last& a, hipStream_t s) {
     const dim3 grid((a.total + 3) / 4);
-    if (a.strips == 1 && (a.OW & 3) == 0) hipLaunchKernelGGL((k_s2_last_fused<CIN, COUT, KH, KW, HB, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_s2_last_fused<CIN, COUT, KH, KW, HB, false>), grid, dim3(256), 0, s, a);
+    const bool vec4 = a.strips == 1 && (a.OW & 3) == 0, bn = a.bn_in.mode != BN_NONE;
+    if (vec4 && bn) hipLaunchKernelGGL((k_s2_last_fused<CIN, COUT, KH, KW, HB, true, true>), grid, dim3(256), 0, s, a);
+    else if (bn) hipLaunchKernelGGL((k_s2_last_fused<CIN, COUT, KH, KW, HB, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_s2_last_fused<CIN, COUT, KH, KW, HB, false, false>), grid, dim3(256), 0, s, a);
 }
 
 template <int CIN, int COUT, int KH, int KW>
@@ -1076,6 +1078,10 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 f.bn_in = bn_of(e, P, BN_BATCH, (double)a.bn_batch * P.hout * P.wout, 1);
                 f.gin = e->fptr(P.grad_off);
                 f.stats_in = e->bn_stats(P.bn_index);
+            }
+            {
+                static const int dbg = env_int("CAE_HEAD_DBG", 0);   // tools/last_phases.py
+                f.dbg = dbg == 4 ? reinterpret_cast<long long*>(e->ws + e->off_scan) : nullptr;
             }
             ProfScope _p(e, "s2_convt_last_fused", l, f4((double)B * (L.in_elems() * 2.0 + L.out_elems())));
             last_fused_dispatch(L, f, s);

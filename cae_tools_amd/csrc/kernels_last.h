@@ -60,6 +60,7 @@ struct S2Last {
     int acc_stride;
     float* gin;              // (B, CIN, H, W) gradient wrt the producer's raw output side (masked by its ReLU)
     double* stats_in;        // producer's [kStatShards][CIN][4] sums (slots 2, 3) or nullptr
+    long long* dbg;          // diagnostics (tools/last_phases.py): 8 wall-clock stamps per workgroup (first 384), or nullptr
 };
 
 constexpr int kLastStripPx = 127;   // pixel columns a strip owns (it computes 128 quad columns)
@@ -75,20 +76,21 @@ __device__ __forceinline__ float from_right(float v, float edge) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
 }
 
+// BN: the input carries the producer's BatchNorm + ReLU (always, unless the decoder has a single layer)
 // VEC4: output rows are 16-byte aligned and there is one strip (OW % 4 == 0, strips == 1): 16-byte target loads
-template <int CIN, int COUT, int KH, int KW, int HB, bool VEC4>
+template <int CIN, int COUT, int KH, int KW, int HB, bool VEC4, bool BN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_s2_last_fused(S2Last a) {
     constexpr int NACC = CIN * COUT * KH * KW;
     constexpr int NRED = NACC + 2 * CIN;
     constexpr int NR = HB + 1;            // quad rows a wave computes: its band + the first row of the next one
     static_assert(KH >= 3 && KH <= 4 && KW >= 3 && KW <= 4, "3- or 4-tap stride-2 kernels");
-    __shared__ float4 cin4[CIN];
     __shared__ float redf[4 * NRED];
     __shared__ double redd[4 * 2 * COUT];
 
+#define LF_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x < 384) a.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool bn = a.bn_in.mode != BN_NONE;
+    LF_STAMP(0);
     const unsigned HW = a.H * a.W, OHW = a.OH * a.OW;
 
     // ---- this wave's band
@@ -103,8 +105,49 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     const int n0 = strip * kLastStripPx + 2 * lane;      // first of the lane's two quad columns = its first pixel column
     const bool multi = a.strips > 1;
 
-    // ---- loads.  Inputs: rows m0-1 .. m0+HB, columns n0, n0+1 (+ column n0-1 for lane 0 of a later strip); clamped
-    // addresses, validity by select.  Targets: output rows 2m, 2m+1 of every quad row, four columns from 2 n0.
+    // ---- loads, in the order their consumers can use them.  The wave's memory counter retires in issue order, so whatever a
+    // value's consumer waits for, it waits for everything issued before it: the small dependent reads (cursor -> permutation
+    // -> target row; BatchNorm sums; weights) go first and the band's bulk behind them, never the other way round.
+    long long bs = 0;
+    const bool indirect = a.perm != nullptr || a.use_cursor != 0;
+    if (indirect) bs = a.st->batch_start;
+    // BatchNorm sums of the producer: lane (8 c + shard) reads that shard's {sum y, sum y^2} of channel c (one 16-byte load)
+    double sa = 0.0, sb = 0.0;
+    float gam[CIN], bet[CIN], rmn[CIN], rvr[CIN];
+    if constexpr (BN) {
+        static_assert(CIN <= 8, "one lane per (channel, shard)");
+        if (lane < 8 * CIN) {
+            const double2 t = *reinterpret_cast<const double2*>(a.bn_in.stats + ((size_t)(lane & 7) * CIN + (lane >> 3)) * 4);
+            sa = t.x;
+            sb = t.y;
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++) {
+            gam[ci] = a.bn_in.gamma[ci];
+            bet[ci] = a.bn_in.beta[ci];
+            rmn[ci] = a.bn_in.rmean[ci];
+            rvr[ci] = a.bn_in.rvar[ci];
+        }
+    }
+    // weights and biases: wave-uniform; moved to scalar registers below (the compiler will not use scalar loads for memory the
+    // kernel's own stores might alias; left to itself it keeps them in vector registers)
+    float wk[NACC], bk[COUT];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) wk[i] = a.w[i];
+#pragma unroll
+    for (int i = 0; i < COUT; i++) bk[i] = a.bias[i];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // the permutation entry is requested here and waited for behind the input loads (branch-free: without a permutation the
+    // load reads a dummy word of the step state)
+    // (the zero offset is hidden from the compiler in a vector register: a load it knows to be uniform is moved to a scalar
+    // register - and waited for - where it is issued)
+    int lane_zero = 0;
+    asm volatile("" : "+v"(lane_zero));
+    const int* perm_src = (a.perm ? a.perm + (bs + b) : reinterpret_cast<const int*>(a.st)) + lane_zero;
+    const int perm_val_v = *perm_src;
+    // Inputs: rows m0-1 .. m0+HB, columns n0, n0+1 (+ column n0-1 for lane 0 of a later strip); clamped addresses, validity
+    // by select.  Targets: output rows 2m, 2m+1 of every quad row, four columns from 2 n0.
     constexpr int NLEFT = VEC4 ? 1 : NR + 1;   // one strip: nothing to the left of lane 0
     float rin[NR + 1][CIN][2], rleft[NLEFT][CIN];
     float4 tgt[NR][COUT][2];
@@ -124,11 +167,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
                 }
             }
         }
-        long long tb = b;
-        if (a.perm || a.use_cursor) {
-            const long long bs = a.st->batch_start;
-            tb = a.perm ? (long long)a.perm[bs + b] : bs + b;
-        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const long long tb = a.perm ? (long long)__builtin_amdgcn_readfirstlane(perm_val_v) : bs + b;   // bs = 0 without a cursor
 #pragma unroll
         for (int r = 0; r < NR; r++) {
 #pragma unroll
@@ -149,20 +190,46 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
                 }
             }
         }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // weights and biases: wave-uniform, read once into scalar registers (the compiler will not use scalar loads for memory
-    // the kernel's own stores might alias; left to itself it keeps them in vector registers)
-    float wk[NACC], bk[COUT];
+    LF_STAMP(1);
 #pragma unroll
-    for (int i = 0; i < NACC; i++) wk[i] = uniform_f(a.w[i]);
+    for (int i = 0; i < NACC; i++) wk[i] = uniform_f(wk[i]);
 #pragma unroll
-    for (int i = 0; i < COUT; i++) bk[i] = uniform_f(a.bias[i]);
-    bn_consts(a.bn_in, cin4, blockIdx.x == 0);
-    __syncthreads();
+    for (int i = 0; i < COUT; i++) bk[i] = uniform_f(bk[i]);
+    // BatchNorm constants {mean, gamma * invstd, beta, invstd} inside the wave (bn_consts' arithmetic): the eight shards of a
+    // channel sit in eight neighbouring lanes - three DPP steps - and lane 8 c hands the sums to everybody
     float4 kc[CIN];
 #pragma unroll
-    for (int ci = 0; ci < CIN; ci++) kc[ci] = bn ? cin4[ci] : make_float4(0.f, 1.f, 0.f, 1.f);
+    for (int ci = 0; ci < CIN; ci++) kc[ci] = make_float4(0.f, 1.f, 0.f, 1.f);
+    if constexpr (BN) {
+        sa += dpp_d<0xB1>(sa); sb += dpp_d<0xB1>(sb);       // quad_perm [1,0,3,2]
+        sa += dpp_d<0x4E>(sa); sb += dpp_d<0x4E>(sb);       // quad_perm [2,3,0,1]
+        sa += dpp_d<0x141>(sa); sb += dpp_d<0x141>(sb);     // row_half_mirror: every lane of an 8-lane group holds the group's sum
+        const long long ba = __builtin_bit_cast(long long, sa), bb = __builtin_bit_cast(long long, sb);
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++) {
+            const int lo1 = __builtin_amdgcn_readlane((int)ba, 8 * ci), hi1 = __builtin_amdgcn_readlane((int)(ba >> 32), 8 * ci);
+            const int lo2 = __builtin_amdgcn_readlane((int)bb, 8 * ci), hi2 = __builtin_amdgcn_readlane((int)(bb >> 32), 8 * ci);
+            const double s1 = __builtin_bit_cast(double, ((long long)hi1 << 32) | (unsigned)lo1);
+            const double s2 = __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned)lo2);
+            const double mu = s1 * a.bn_in.inv_count;
+            double var = s2 * a.bn_in.inv_count - mu * mu;
+            var = var < 0.0 ? 0.0 : var;
+            const float mean = (float)mu;
+            const float invstd = 1.0f / sqrtf((float)(var + (double)a.bn_in.eps));
+            kc[ci] = make_float4(mean, uniform_f(gam[ci]) * invstd, uniform_f(bet[ci]), invstd);
+            if (blockIdx.x == 0 && tid == 0 && a.bn_in.update) {   // the designated consumer of this BatchNorm's forward pass
+                a.bn_in.saved[2 * ci] = mean;
+                a.bn_in.saved[2 * ci + 1] = invstd;
+                a.bn_in.rmean[ci] = (1.f - a.bn_in.momentum) * rmn[ci] + a.bn_in.momentum * mean;
+                a.bn_in.rvar[ci] = (1.f - a.bn_in.momentum) * rvr[ci] + a.bn_in.momentum * (float)(var * a.bn_in.unbias);
+            }
+        }
+    }
 
+    LF_STAMP(2);
     float dw[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; i++) dw[i] = 0.f;
@@ -178,7 +245,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
         const int y = m0 - 1 + r;
         const bool rowok = y >= 0 && y < a.H;
         float v0 = rin[r][ci][0], v1 = rin[r][ci][1], vl = VEC4 ? 0.f : rleft[VEC4 ? 0 : r][ci];
-        if (bn) {
+        if constexpr (BN) {
             v0 = fmaxf(0.f, fmaf(v0 - kc[ci].x, kc[ci].y, kc[ci].z));
             v1 = fmaxf(0.f, fmaf(v1 - kc[ci].x, kc[ci].y, kc[ci].z));
             vl = fmaxf(0.f, fmaf(vl - kc[ci].x, kc[ci].y, kc[ci].z));
@@ -247,12 +314,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
                             const int ox = 2 * (n0 + q) + px;
                             const bool valid = rowok && ox < a.OW;
                             const float yh = sigmoid_fast(acc[q][py][px]);
-                            const float d = yh - tv[2 * q + px];
-                            const float gv = valid ? (2.0f * d * a.inv_count) * (yh * (1.0f - yh)) : 0.f;
+                            // an output outside the map has no error: d = 0 makes its loss term and its gradient vanish
+                            const float d = valid ? yh - tv[2 * q + px] : 0.f;
+                            const float gv = (2.0f * d * a.inv_count) * (yh * (1.0f - yh));
                             g[co][q][py][px] = gv;
                             // a quad column is counted by the strip that owns it: the last lane's second quad is the next strip's
-                            const bool own = own_row && valid && (q == 0 || lane < 63 || last_strip);
-                            if (own) { ls[co] = fmaf(d, d, ls[co]); gs[co] += gv; }
+                            // (selects, not branches: a wave runs alone on its SIMD and every exec-mask branch is a bubble)
+                            const bool own = own_row && (VEC4 || q == 0 || lane < 63 || last_strip);   // VEC4: one strip, owns all it computes
+                            const float dl = own ? d : 0.f;
+                            ls[co] = fmaf(dl, dl, ls[co]);
+                            gs[co] += own ? gv : 0.f;
                         }
                 }
             }
@@ -271,7 +342,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
                     const float* wc = &wk[(ci * COUT + co) * KH * KW];
 #pragma unroll
                     for (int q = 0; q < 2; q++) {
-                        const bool ownq = q == 0 || lane < 63 || last_strip;
+                        const bool ownq = VEC4 || q == 0 || lane < 63 || last_strip;
 #pragma unroll
                         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -294,35 +365,48 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
             // ---- pixel row y = m-1: complete, mask, store, BatchNorm-backward sums; then the new carry
             const int y = m - 1;
             const bool emit = r >= 1 && y < a.H;        // uniform; r == 0 completes a row of the band above (it does so itself)
+            float tj1[CIN][2], tj0[CIN][2];
 #pragma unroll
             for (int ci = 0; ci < CIN; ci++) {
                 // pixel n0: quad 0's i = 0 shares + quad 1's i = 1 shares; pixel n0+1: quad 1's i = 0 + the right neighbour's quad 0, i = 1
-                const float t0j1 = P[ci][0][1][0] + P[ci][1][1][1], t0j0 = P[ci][0][0][0] + P[ci][1][0][1];
-                const float t1j1 = P[ci][1][1][0] + from_right(P[ci][0][1][1], 0.f);
-                const float t1j0 = P[ci][1][0][0] + from_right(P[ci][0][0][1], 0.f);
-                if (emit) {
-                    float gv0 = carry[ci][0] + t0j1, gv1 = carry[ci][1] + t1j1;
-                    const float raw0 = rin[r][ci][0], raw1 = rin[r][ci][1];
-                    const bool p0 = n0 < a.W, p1 = n0 + 1 < a.W && lane < 63;
-                    if (bn) {
-                        const float e0 = raw0 - kc[ci].x, e1 = raw1 - kc[ci].x;
+                tj1[ci][0] = P[ci][0][1][0] + P[ci][1][1][1];
+                tj0[ci][0] = P[ci][0][0][0] + P[ci][1][0][1];
+                tj1[ci][1] = P[ci][1][1][0] + from_right(P[ci][0][1][1], 0.f);
+                tj0[ci][1] = P[ci][1][0][0] + from_right(P[ci][0][0][1], 0.f);
+            }
+            if (emit) {
+                const bool p0 = n0 < a.W, p1 = n0 + 1 < a.W && lane < 63;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ci++) {
+                    float gv0 = carry[ci][0] + tj1[ci][0], gv1 = carry[ci][1] + tj1[ci][1];
+                    if constexpr (BN) {
+                        const float e0 = rin[r][ci][0] - kc[ci].x, e1 = rin[r][ci][1] - kc[ci].x;
                         gv0 = fmaf(e0, kc[ci].y, kc[ci].z) > 0.f ? gv0 : 0.f;
                         gv1 = fmaf(e1, kc[ci].y, kc[ci].z) > 0.f ? gv1 : 0.f;
-                        if (p0) { d1[ci] += gv0; d2[ci] = fmaf(gv0, e0 * kc[ci].w, d2[ci]); }
-                        if (p1) { d1[ci] += gv1; d2[ci] = fmaf(gv1, e1 * kc[ci].w, d2[ci]); }
+                        const float s0 = p0 ? gv0 : 0.f, s1 = p1 ? gv1 : 0.f;
+                        d1[ci] += s0 + s1;
+                        d2[ci] = fmaf(s0, e0 * kc[ci].w, fmaf(s1, e1 * kc[ci].w, d2[ci]));
                     }
+                    // one exec-mask branch per channel: the second store of a lane without a second pixel repeats its first
                     float* gp = a.gin + (size_t)(b * CIN + ci) * HW + (unsigned)y * a.W + n0;
-                    if (p0) gp[0] = gv0;
-                    if (p1) gp[1] = gv1;
+                    if (p0) {
+                        gp[0] = gv0;
+                        gp[p1 ? 1 : 0] = p1 ? gv1 : gv0;
+                    }
                 }
-                carry[ci][0] = t0j0;
-                carry[ci][1] = t1j0;
+            }
+#pragma unroll
+            for (int ci = 0; ci < CIN; ci++) {
+                carry[ci][0] = tj0[ci][0];
+                carry[ci][1] = tj0[ci][1];
 #pragma unroll
                 for (int k = 0; k < 3; k++) actP[ci][k] = actN[ci][k];
             }
+            if (r == 0) LF_STAMP(3);
         });
     }
 
+    LF_STAMP(4);
     // ---- reductions: wave (DPP), workgroup (LDS), then one fp64 atomic per value
 #pragma unroll
     for (int i = 0; i < NACC; i++) {
@@ -366,6 +450,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
             else atomicAdd(&a.bias_acc[(size_t)shard * a.acc_stride + co], s);
         }
     }
+    LF_STAMP(5);
+#undef LF_STAMP
 }
 
 }  // namespace cae
