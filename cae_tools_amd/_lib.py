@@ -67,6 +67,8 @@ SIGNATURES = {
     "cae_dp_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cae_eval_step": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "cae_score": (C.c_int, [_P, _P, C.c_int, _P]),
+    "cae_encode": (C.c_int, [_P, _P, C.c_int, _P]),
+    "cae_decode": (C.c_int, [_P, _P, C.c_int, _P]),
     "cae_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cae_loss_slots": (C.c_int, [_P]),
     "cae_sync": (C.c_int, [_P]),

@@ -299,6 +299,11 @@ struct StepArgs {
     // dp_sync additionally all-reduces every BatchNorm sum table in-stream (SyncBN) instead of calling sync_fn
     bool dp = false, dp_sync = false;
     int cursor_inc = -1;   // samples the cursor moves per step (-1: batch; the global batch under data parallelism)
+    // module-level forward (cae_encode / cae_decode): 0 = the whole network, 1 = encoder only (x_direct -> z_out),
+    // 2 = decoder only (z_in -> yhat); eval mode, per-layer launches
+    int part = 0;
+    const float* z_in = nullptr;
+    float* z_out = nullptr;
     bool syncing() const { return sync_fn != nullptr || dp_sync; }
     int inc() const { return cursor_inc >= 0 ? cursor_inc : batch; }
 };
@@ -826,7 +831,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
 
     HeadArgs head;
     size_t head_lds = 0;
-    const bool fused_head = head_plan(e, a, head, head_lds);
+    const bool fused_head = a.part == 0 && head_plan(e, a, head, head_lds);
     if (fused_head) {
         head.x = a.x_direct ? a.x_direct : e->ds_x[a.which];
         head.perm = a.x_direct ? nullptr : a.perm;
@@ -844,7 +849,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
                            head_lds, s, head);
     }
     // ---- encoder convs (encoder.py:40-46)
-    for (size_t l = 0; !fused_head && l < e->enc.size(); l++) {
+    for (size_t l = 0; !fused_head && a.part != 2 && l < e->enc.size(); l++) {
         const ConvLayer& L = e->enc[l];
         ConvGeom g{B, L.cout, L.hout, L.wout, L.cin, L.hin, L.win, L.kh, L.kw, L.stride};
         Src big;
@@ -877,8 +882,9 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
         const ConvLayer& P = e->enc.back();
         const int hw = P.hout * P.wout;
         BnDesc bni = bn_of(e, P, act_mode, (double)a.bn_batch * hw, 1);
-        const float* in = e->fptr(P.act_off);
-        for (int i = 0; i < 4; i++) {
+        const float* in = a.part == 2 ? a.z_in : e->fptr(P.act_off);
+        const int fc_lo = a.part == 2 ? 2 : 0, fc_hi = a.part == 1 ? 2 : 4;
+        for (int i = fc_lo; i < fc_hi; i++) {
             const FcLayer& F = e->fc[i];
             ProfScope _p(e, e->use_s2 ? "linear_fwd_mfma" : "linear_fwd", i, f4((double)B * (F.nin + F.nout) + (double)F.nin * F.nout));
             if (e->use_s2) {
@@ -902,6 +908,10 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
                                    e->params + F.b_off, F.relu ? 1 : 0, e->fptr(F.act_off));
             }
             in = e->fptr(F.act_off);
+        }
+        if (a.part == 1) {   // the latent vector leaves the engine: (batch, latent) fp32, contiguous like the Linear's output
+            HIP_TRY(hipMemcpyAsync(a.z_out, e->fptr(e->fc[1].act_off), sizeof(float) * (size_t)B * e->fc[1].nout, hipMemcpyDeviceToDevice, s));
+            return CAE_OK;
         }
     }
     // ---- decoder conv-transposes (decoder.py:40-48) + sigmoid (:77) + MSELoss (conv_ae_model.py:303)
@@ -2058,6 +2068,26 @@ int cae_score(cae_engine* e, const float* x, int batch, float* y) {
     if (!x || !y) return fail(CAE_ERR_ARG, "cae_score: null pointer");
     if (batch < 1 || batch > e->max_batch) return fail(CAE_ERR_ARG, "batch %d outside [1, %d]", batch, e->max_batch);
     StepArgs a{0, nullptr, batch, batch, batch, false, false, x, y, false};
+    return run_op(e, OP_EVAL, a, false);
+}
+
+int cae_encode(cae_engine* e, const float* x, int batch, float* z) {
+    if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+    if (!x || !z) return fail(CAE_ERR_ARG, "cae_encode: null pointer");
+    if (batch < 1 || batch > e->max_batch) return fail(CAE_ERR_ARG, "batch %d outside [1, %d]", batch, e->max_batch);
+    StepArgs a{0, nullptr, batch, batch, batch, false, false, x, nullptr, false};
+    a.part = 1;
+    a.z_out = z;
+    return run_op(e, OP_EVAL, a, false);
+}
+
+int cae_decode(cae_engine* e, const float* z, int batch, float* y) {
+    if (!e || !e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+    if (!z || !y) return fail(CAE_ERR_ARG, "cae_decode: null pointer");
+    if (batch < 1 || batch > e->max_batch) return fail(CAE_ERR_ARG, "batch %d outside [1, %d]", batch, e->max_batch);
+    StepArgs a{0, nullptr, batch, batch, batch, false, false, nullptr, y, false};
+    a.part = 2;
+    a.z_in = z;
     return run_op(e, OP_EVAL, a, false);
 }
 

@@ -469,6 +469,34 @@ class HipEngine(EnginePlan):
         out.record_stream(self.stream)
         return out
 
+    def _module_forward(self, fn, x, row_shape, what):
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise CaeError(f"{what}() needs an fp32 CUDA tensor")
+        x = x.contiguous()
+        out = torch.empty((x.shape[0],) + tuple(row_shape), dtype=torch.float32, device=self.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        done = 0
+        while done < x.shape[0]:
+            n = min(self.max_batch, x.shape[0] - done)
+            check(fn(self.handle, x[done:done + n].data_ptr(), n, out[done:done + n].data_ptr()))
+            done += n
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        x.record_stream(self.stream)
+        out.record_stream(self.stream)
+        return out
+
+    def encode(self, x):
+        """Encoder.forward (encoder.py:60-64) in eval mode: (B,C,h,w) fp32 CUDA tensor -> (B, latent)"""
+        if tuple(x.shape[1:]) != tuple(self.in_shape):
+            raise CaeError(f"encode() expects rows of shape {tuple(self.in_shape)}, got {tuple(x.shape[1:])}")
+        return self._module_forward(self.lib.cae_encode, x, (self.latent_size,), "encode")
+
+    def decode(self, z):
+        """Decoder.forward (decoder.py:73-78) in eval mode: (B, latent) fp32 CUDA tensor -> (B,C,H,W), sigmoid applied"""
+        if z.dim() != 2 or z.shape[1] != self.latent_size:
+            raise CaeError(f"decode() expects (batch, {self.latent_size}), got {tuple(z.shape)}")
+        return self._module_forward(self.lib.cae_decode, z, self.out_shape, "decode")
+
     def sync(self):
         check(self.lib.cae_sync(self.handle))
 

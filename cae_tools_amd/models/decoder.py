@@ -6,6 +6,8 @@ after the last), sigmoid.  Initialisation (:55-71): every layer first draws its 
 init, then ConvTranspose2d weights are re-drawn kaiming_normal(fan_out, relu), Linear weights
 kaiming_normal(fan_out, relu) or xavier_normal when out_features == C*y*x, biases zeroed, in
 module registration order.
+Calling the module on its own (decoder.py:73-78) runs the attached engine through cae_decode, EVAL
+mode; training and scoring run encoder and decoder fused.  An unattached module raises.
 """
 from torch.nn import init
 
@@ -49,5 +51,11 @@ class Decoder(ParamBag):
         self._engine = engine
 
     def forward(self, z):
-        raise RuntimeError("Decoder.forward on its own is not a product path: the encoder and decoder "
-                           "run fused in libcae_hip (use ConvAEModel.score / apply / train)")
+        """z (B, encoded_space_dim) fp32 CUDA tensor -> y (B, C, H, W) in [0, 1]; eval mode, on the attached engine
+        (whose parameter arena holds the live weights: HipEngine.load_state / ConvAEModel put them there)"""
+        if self._engine is None:
+            raise RuntimeError("Decoder.forward needs an attached HipEngine (ConvAEModel attaches one when it builds or "
+                               "loads a model): there is no CPU path")
+        return self._engine.decode(z)
+
+    __call__ = forward

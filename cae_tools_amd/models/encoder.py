@@ -3,8 +3,10 @@
 Mirrors the constructor / forward / state_dict surface of the reference Encoder
 (src/cae_tools/models/encoder.py:36-64): per layer Conv2d(k, stride) -> BatchNorm2d -> ReLU,
 flatten, Linear(C*y*x, fc) -> ReLU -> Linear(fc, latent); PyTorch default initialisation.
-The arithmetic runs in libcae_hip (see ConvAEModel / HipEngine); calling this module directly
-scores through the engine it is attached to.
+The arithmetic runs in libcae_hip (see ConvAEModel / HipEngine).  Training and scoring run the
+encoder and decoder fused; calling this module on its own (encoder.py:60-64) runs the engine it is
+attached to through cae_encode: EVAL mode (running BatchNorm statistics), there is no train-mode
+module-level forward.  A module that is not attached to an engine raises.
 """
 import torch
 
@@ -33,5 +35,11 @@ class Encoder(ParamBag):
         self._engine = engine
 
     def forward(self, x):
-        raise RuntimeError("Encoder.forward on its own is not a product path: the encoder and decoder "
-                           "run fused in libcae_hip (use ConvAEModel.score / apply / train)")
+        """x (B, C, h, w) fp32 CUDA tensor -> z (B, encoded_space_dim); eval mode, on the attached engine
+        (whose parameter arena holds the live weights: HipEngine.load_state / ConvAEModel put them there)"""
+        if self._engine is None:
+            raise RuntimeError("Encoder.forward needs an attached HipEngine (ConvAEModel attaches one when it builds or "
+                               "loads a model): there is no CPU path")
+        return self._engine.encode(x)
+
+    __call__ = forward

@@ -6,8 +6,8 @@
  * reference sites, cited per entry point as file:line under src/cae_tools/:
  *
  *   models/model_sizer.py:16-67     LayerSpec                     -> cae_layer_spec
- *   models/encoder.py:36-64         Encoder.__init__/forward      -> cae_engine_create / cae_score / cae_train_step
- *   models/decoder.py:24-78         Decoder.__init__/forward      -> (same engine)
+ *   models/encoder.py:36-64         Encoder.__init__/forward      -> cae_engine_create / cae_encode (module alone) / cae_score / cae_train_step
+ *   models/decoder.py:24-78         Decoder.__init__/forward      -> (same engine) / cae_decode (module alone)
  *   models/conv_ae_model.py:185-203 ConvAEModel.__train_epoch     -> cae_set_cursor + cae_train_step per batch + cae_read_losses
  *   models/conv_ae_model.py:205-221 ConvAEModel.__test_epoch      -> cae_eval_step per batch + cae_read_losses
  *   models/conv_ae_model.py:223-239 ConvAEModel.score             -> cae_score
@@ -194,6 +194,13 @@ int cae_eval_step(cae_engine* e, int which, const int32_t* perm_dev, int batch);
 /* score() for one batch (conv_ae_model.py:223-239): eval-mode forward of x_dev (batch, in_c,
  * in_h, in_w) into y_dev (batch, out_c, out_h, out_w). */
 int cae_score(cae_engine* e, const float* x_dev, int batch, float* y_dev);
+
+/* Module-level forward of the reference's two torch modules, eval mode (running BatchNorm statistics), one batch:
+ *   Encoder.forward(x) -> z   (encoder.py:60-64):  x_dev (batch, in_c, in_h, in_w) -> z_dev (batch, latent)
+ *   Decoder.forward(z) -> y   (decoder.py:73-78):  z_dev (batch, latent) -> y_dev (batch, out_c, out_h, out_w), sigmoid applied
+ * cae_decode(cae_encode(x)) equals cae_score(x).  Asynchronous on the engine's stream. */
+int cae_encode(cae_engine* e, const float* x_dev, int batch, float* z_dev);
+int cae_decode(cae_engine* e, const float* z_dev, int batch, float* y_dev);
 
 /* Blocking: wait for the stream, copy `count` per-step mean losses starting at slot `first`
  * to host memory, and zero those slots. */

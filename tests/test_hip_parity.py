@@ -56,6 +56,52 @@ def test_eval_forward(name, specialised):
     np.testing.assert_allclose(projections(y, 77), case["eval0/y_proj"], rtol=0, atol=2e-3)
 
 
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_module_level_forward(name):
+    """Encoder.forward(x) -> z and Decoder.forward(z) -> y on their own (reference encoder.py:60-64, decoder.py:73-78), eval
+    mode, through cae_encode / cae_decode: against the oracle's two module functions, the reference's stored latent, and the
+    fused scoring path."""
+    from oracle import cae_oracle as orc
+    from cae_tools_amd.models.encoder import Encoder
+    from cae_tools_amd.models.decoder import Decoder
+    case = GoldenCase(name)
+    eng = _engine(case)
+    x = torch.from_numpy(case.x).cuda()
+    z = eng.encode(x)
+    om = _oracle(case)
+    with torch.no_grad():
+        z_ref = orc.encoder_forward(om.spec, om.enc, torch.from_numpy(case.x), train=False)
+        y_ref = orc.decoder_forward(om.spec, om.dec, z_ref, train=False)
+    tol_z = 2e-5 * max(1.0, float(z_ref.abs().max()))
+    assert tuple(z.shape) == tuple(z_ref.shape)
+    assert np.abs(z.cpu().numpy() - z_ref.numpy()).max() <= tol_z
+    np.testing.assert_allclose(z.cpu().numpy(), case["eval0/latent"], rtol=0, atol=tol_z)
+    # the decoder alone, from the ORACLE's latent (so that an encoder error cannot hide in it), and composed
+    y = eng.decode(z_ref.cuda())
+    assert np.abs(y.cpu().numpy() - y_ref.numpy()).max() <= 1e-5
+    y2 = eng.decode(z).cpu().numpy()
+    assert np.abs(y2 - eng.score(x).cpu().numpy()).max() <= 1e-6
+    np.testing.assert_allclose(subsample(y2), case["eval0/y_sub"], rtol=0, atol=1e-5)
+    # the module classes bind to the same entry points once attached; unattached they refuse (no CPU path)
+    layers = case.spec
+    from cae_tools_amd.models.model_sizer import ModelSpec
+    ms = ModelSpec()
+    ms.load(layers)
+    enc = Encoder(ms.get_input_layers(), encoded_space_dim=case.meta["latent"], fc_size=case.meta["fc"])
+    dec = Decoder(ms.get_output_layers(), encoded_space_dim=case.meta["latent"], fc_size=case.meta["fc"])
+    with pytest.raises(RuntimeError):
+        enc(x)
+    with pytest.raises(RuntimeError):
+        dec(z)
+    enc.attach(eng)
+    dec.attach(eng)
+    assert torch.equal(enc(x), z)
+    assert np.abs(dec(enc.forward(x)).cpu().numpy() - y2).max() == 0.0
+    # partial batches larger than the engine's max_batch are walked in chunks
+    xx = torch.cat([x, x, x])[: eng.max_batch + 1]
+    assert torch.equal(eng.encode(xx)[: x.shape[0]], z)
+
+
 @pytest.mark.parametrize("graph,specialised", [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("name", MODEL_CASES)
 def test_train_forward_backward(name, graph, specialised):

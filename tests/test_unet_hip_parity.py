@@ -255,6 +255,56 @@ def test_benchmark_geometry_full_size_against_oracle():
     np.testing.assert_allclose(eng.score(x).cpu().numpy(), o.eval_forward(x).numpy(), rtol=0, atol=3e-5)
 
 
+def test_benchmark_geometry_at_the_stated_batch():
+    """BASELINE cfg3 at its STATED batch, 32 (the test above runs the same layers at batch 5): grid sizes, split-K choices and
+    the pressure on the BatchNorm-sum shards change with the batch.  Train-mode loss parts and a sample of gradients against
+    the CPU oracle at batch 32; eval rows equal to the same rows scored at batch 5 (eval mode is per sample); every gradient
+    finite; one AdamW step on the batch lowers its loss."""
+    from cae_tools_amd.models.unet import Decoder, Encoder, unet_layer_spec
+    from cae_tools_amd.unet_engine import UnetEngine
+    from oracle import unet_oracle as uo
+    torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 8 else 8))
+    spec = unet_layer_spec(3, 3, (256, 256), [32, 64, 128, 256])
+    (fc, latent, B) = (128, 32, 32)
+    torch.manual_seed(11)
+    enc = Encoder(spec.get_input_layers(), latent, fc)
+    dec = Decoder(spec.get_output_layers(), latent, fc)
+    g = torch.Generator().manual_seed(14)
+    x = torch.rand((B, 3, 256, 256), generator=g)
+    t = torch.rand((B, 3, 256, 256), generator=g)
+    m = (torch.rand((B, 1, 256, 256), generator=g) < 0.9).float()
+    eng = UnetEngine(spec, fc, latent, B, device="cuda:0")
+    eng.load_state(enc.state_dict(), dec.state_dict())
+    eng.set_hyper(dropout_rate=0.0, seed=21, lr=1e-4)
+    eng.set_dataset(0, x, t, m)
+    # eval: rows of the batch-32 call == the same rows scored five at a time
+    y32 = eng.score(x).cpu().numpy()
+    small = UnetEngine(spec, fc, latent, 5, device="cuda:0")
+    small.load_state(enc.state_dict(), dec.state_dict())
+    y5 = small.score(x[:5]).cpu().numpy()
+    assert np.abs(y32[:5] - y5).max() <= 1e-6
+    assert np.isfinite(y32).all()
+    # train-mode step at batch 32 against the oracle (dropout off: the reference's arithmetic exactly)
+    o = uo.UnetOracle(spec.save(), enc.state_dict(), dec.state_dict(), dropout_rate=0.0, seed=21)
+    (mse, pl, _) = o.loss_and_grads(x, t, m)
+    want = o.grads()
+    got = _grad_dict(eng, eng.forward_backward(0, None, 0, B, slot=0))
+    first = eng.read_losses(0, 1)[0]
+    np.testing.assert_allclose(first, [mse, pl], rtol=3e-5)
+    for k, w in want.items():
+        gv = got[k].numpy().astype(np.float64)
+        assert np.isfinite(gv).all(), k
+        if _feeds_batchnorm(k):
+            continue
+        wv = w.numpy().astype(np.float64)
+        assert np.linalg.norm(gv - wv) <= 2e-2 * max(np.linalg.norm(wv), 1e-9), k
+    # one small optimiser step on this batch (first-order regime), then the same batch again: the loss went down
+    eng.train_step(0, None, 0, B, slot=1)
+    eng.forward_backward(0, None, 0, B, slot=2)
+    after = eng.read_losses(2, 1)[0]
+    assert after[0] + after[1] < first[0] + first[1]
+
+
 def test_mfma_path_non_square_odd_channel_counts():
     """96x160 maps, channels 16 / 40 / 72 (every tile shape partly filled), 2 -> 5 channels, batch 3, per-channel mask"""
     from cae_tools_amd.models.unet import Decoder, Encoder, unet_layer_spec

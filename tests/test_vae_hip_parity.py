@@ -116,6 +116,39 @@ def test_benchmark_geometry_cfg5():
     assert np.linalg.norm(gv - wv) <= 1e-2 * np.linalg.norm(wv)
 
 
+def test_benchmark_geometry_cfg5_at_the_stated_batch():
+    """BASELINE cfg5 at its STATED batch, 16 (the test above runs batch 2): loss parts against the definition at batch 16,
+    eval rows equal to the same rows scored at batch 2 (eval mode is per sample), finite gradients, and one Adam step on the
+    batch lowers its loss.  PARITY UNPINNED with respect to the reference (no source for this model), like this whole file."""
+    from oracle import vae_oracle as vo
+    torch.set_num_threads(8)
+    (fc, latent, B) = (128, 32, 16)
+    (spec, enc, dec, x, t) = _setup((64, 64), (512, 512), fc, latent, B, seed=13)
+    eng = _engine(spec, enc, dec, fc, latent, B, seed=3, lr=1e-4)
+    eng.set_dataset(0, x, t)
+    y16 = eng.score(x).cpu().numpy()
+    small = _engine(spec, enc, dec, fc, latent, 2, seed=3)
+    assert np.abs(y16[:2] - small.score(x[:2]).cpu().numpy()).max() <= 1e-6
+    o = vo.VaeOracle(spec.save(), enc.state_dict(), dec.state_dict(), seed=3)
+    (parts, _) = o.loss_and_grads(x, t)
+    g = _grad_dict(eng, eng.forward_backward(0, None, 0, B, slot=0))
+    first = eng.read_losses(0, 1)[0]
+    np.testing.assert_allclose(first[:3], parts, rtol=5e-5, atol=1e-7)
+    for k, v in g.items():
+        assert np.isfinite(v.numpy()).all(), k
+    k = "dec/decoder_conv.%d.weight" % (3 * (len(spec.get_output_layers()) - 1))
+    (gv, wv) = (g[k].numpy().astype(np.float64), o.grads()[k].numpy().astype(np.float64))
+    assert np.linalg.norm(gv - wv) <= 1e-2 * np.linalg.norm(wv)
+    # one small Adam step on this batch, then the batch again with the SAME reparameterisation noise (the noise is a hash of
+    # (seed, step): the step counter is put back): the training loss went down
+    eng.set_step(0)
+    eng.train_step(0, None, 0, B, slot=1)
+    eng.set_step(0)
+    eng.forward_backward(0, None, 0, B, slot=2)
+    after = eng.read_losses(2, 1)[0]
+    assert sum(after[:3]) < sum(first[:3])
+
+
 def test_geometry_errors():
     from cae_tools_amd._lib import CaeError
     from cae_tools_amd.models.model_sizer import create_model_spec
