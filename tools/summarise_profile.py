@@ -61,6 +61,17 @@ def main():
                         f'{float(r["AverageNs"]) / 1e3:.2f}', r["Percentage"], f'{float(r["MinNs"]) / 1e3:.2f}',
                         f'{float(r["MaxNs"]) / 1e3:.2f}'])
     order = json.load(open(os.path.join(SRC, "launch_order.json")))
+    # per-launch kernel durations of the --kernel-trace pass, by bench.py's labels (bench.py calibrates its event brackets on them)
+    trace_rows = list(csv.DictReader(open(os.path.join(SRC, "trace", "t_kernel_trace.csv"))))
+    tsteps = per_step_sequences([r for r in trace_rows if "cae::" in r["Kernel_Name"]])
+    tsteps = [st for st in tsteps if len(st) == len(order)][2:]
+    if tsteps:
+        avg = {}
+        for i, (label, _) in enumerate(order):
+            d = [(int(st[i]["End_Timestamp"]) - int(st[i]["Start_Timestamp"])) / 1e3 for st in tsteps]
+            avg[label] = sum(d) / len(d)
+        with open(os.path.join(DST, "kernel_trace_avg_us.json"), "w") as f:
+            json.dump(avg, f, indent=1)
     fetch = counter_per_launch(os.path.join(SRC, "fetch", "f_counter_collection.csv"), "FETCH_SIZE")
     write = counter_per_launch(os.path.join(SRC, "write", "w_counter_collection.csv"), "WRITE_SIZE")
     assert len(fetch) == len(write) == len(order), (len(fetch), len(write), len(order))
@@ -86,6 +97,20 @@ def main():
             w.writerow(["launch", "kernel", "label"] + names)
             for i, (label, _) in enumerate(order):
                 w.writerow([i, cols[names[0]][i][0], label] + [f"{cols[n][i][1]:.4g}" for n in names])
+    mp = os.path.join(SRC, "mfma", "m_counter_collection.csv")
+    if os.path.exists(mp):
+        names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32"]
+        try:
+            cols = {n: counter_per_launch(mp, n) for n in names}
+            with open(os.path.join(DST, f"{tag}_mfma_counters.csv"), "w") as f:
+                w = csv.writer(f)
+                # SQ_VALU_MFMA_BUSY_CYCLES counts per SIMD: 4.0 = all four matrix pipes of every busy CU busy all the time
+                w.writerow(["launch", "kernel", "label"] + names + ["mfma_busy_over_busy_cu(4=all four SIMDs)"])
+                for i, (label, _) in enumerate(order):
+                    (b, c) = (cols[names[0]][i][1], cols[names[1]][i][1])
+                    w.writerow([i, cols[names[0]][i][0], label] + [f"{cols[n][i][1]:.4g}" for n in names] + [f"{b / c:.3f}" if c else ""])
+        except Exception as ex:      # a counter the pass could not collect
+            print("mfma counters:", ex)
     bench = open(os.path.join(SRC, "bench.json")).read().strip()
     with open(os.path.join(DST, f"{tag}_bench_under_rocprof.json"), "w") as f:
         f.write(bench + "\n")
