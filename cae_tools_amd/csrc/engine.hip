@@ -17,6 +17,7 @@
 #include "kernels_generic.h"
 #include "kernels_s2.h"
 #include "kernels_last.h"
+#include "kernels_rows.h"
 #include "kernels_gemm.h"
 #include "kernels_igemm.h"
 #include "kernels_ctlds.h"
@@ -465,6 +466,44 @@ void s2_bwd_dispatch(const ConvLayer& L, const S2Bwd& a, hipStream_t s) {
     S2_SHAPES(PAIR)
 #undef PAIR
 #undef ONE
+}
+
+// ---- row-streaming backward of the thin middle layers (kernels_rows.h) ---------------------------------------------------
+// false: the layer does not fit (shape, kernel size, map wider than a wave); the caller runs k_s2_bwd2 / k_s2_bwd_split
+template <int CIN, int CT, int COUT, int HB, int D>
+void rows_go(S2Rows a, int lw, hipStream_t s) {
+    constexpr int NB = 4 / (CIN / CT);
+    const int hmax = a.H > a.QH - 1 ? a.H : a.QH - 1;
+    a.bands = (hmax + HB - 1) / HB;
+    const int imgs = 64 / lw;
+    a.groups = (a.B + imgs - 1) / imgs;
+    const dim3 grid((unsigned)(a.groups * ((a.bands + NB - 1) / NB)));
+    if (imgs == 1) hipLaunchKernelGGL((k_s2_bwd_rows<CIN, CT, COUT, 3, 3, HB, 1, D>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_s2_bwd_rows<CIN, CT, COUT, 3, 3, HB, 2, D>), grid, dim3(256), 0, s, a);
+}
+
+bool rows_bwd_ok(const cae_engine* e, const ConvLayer& L) {
+    static const int enabled = env_int("CAE_ROWS", 1);            // env: A/B measurements only
+    if (!enabled || !s2_eligible(e, L) || L.kh != 3 || L.kw != 3 || !L.has_bn) return false;
+    const int qw = (L.wout + 1) / 2;
+    const int lw = qw <= 32 ? 32 : 64;
+    if (qw > 64 || L.win > lw - 1) return false;      // a lane per quad column; the last lane of an image owns no pixel
+    return (L.cin == 4 && L.cout == 2) || (L.cin == 8 && L.cout == 4);
+}
+
+void rows_bwd_launch(const ConvLayer& L, S2Rows a, hipStream_t s) {
+    static const int hb42 = env_int("CAE_ROWS_HB42", 2), hb84 = env_int("CAE_ROWS_HB84", 2);   // env: tuning only
+    a.QH = (L.hout + 1) / 2;
+    const int lw = (L.wout + 1) / 2 <= 32 ? 32 : 64;
+    // short bands with every row's loads issued up front (a wave pays the memory latency once) against tall bands that load one
+    // row ahead (less re-reading at the band edges, but a round trip per row: a wave is alone on its SIMD)
+    if (L.cin == 4) {
+        if (hb42 == 4) rows_go<4, 4, 2, 4, 1>(a, lw, s);
+        else rows_go<4, 4, 2, 2, 3>(a, lw, s);
+    } else {
+        if (hb84 == 4) rows_go<8, 2, 4, 4, 1>(a, lw, s);
+        else rows_go<8, 2, 4, 2, 3>(a, lw, s);
+    }
 }
 
 // ---- last decoder layer of a training step as one launch (kernels_last.h): forward + sigmoid + MSE + backward ---------
@@ -1097,6 +1136,32 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             last_fused_dispatch(L, f, s);
             if (l > 0)
                 if (int rc = sync_bn_table(e, a, e->dec[l - 1].bn_index)) return rc;
+            continue;
+        }
+        if (!last && l > 0 && e->dec[l - 1].has_bn && rows_bwd_ok(e, L)) {
+            const ConvLayer& P = e->dec[l - 1];
+            S2Rows f;
+            memset(&f, 0, sizeof f);
+            f.B = B; f.H = L.hin; f.W = L.win; f.OH = L.hout; f.OW = L.wout;
+            f.g = gy.p; f.yout = gy.q; f.bn_out = bng;
+            f.ain = ain.p; f.bn_in = bna;
+            f.w = e->params + L.w_off;
+            f.gin = e->fptr(P.grad_off);
+            f.stats_in = e->bn_stats(P.bn_index);
+            f.wacc = e->sgacc() + L.sh_w;
+            f.wacc_stride = e->segs.n;
+            f.bg.stats = e->bn_stats(L.bn_index);
+            f.bg.gamma_acc = acc + L.gamma_off;
+            f.bg.beta_acc = acc + L.beta_off;
+            f.bg.C = L.cout;
+            f.bg.scale = 1.0 / a.world;
+            {
+                static const int dbg = env_int("CAE_HEAD_DBG", 0), dbg_layer = env_int("CAE_DBG_LAYER", 4);   // tools/last_phases.py rows
+                f.dbg = dbg == 5 && l == dbg_layer ? reinterpret_cast<long long*>(e->ws + e->off_scan) : nullptr;
+            }
+            ProfScope _p(e, "s2_convt_bwd", l, f4((double)B * (L.out_elems() * 2.0 + L.in_elems() * 2.0)));
+            rows_bwd_launch(L, f, s);
+            if (int rc = sync_bn_table(e, a, P.bn_index)) return rc;
             continue;
         }
         if (s2_eligible(e, L)) {

@@ -77,6 +77,32 @@ __device__ __forceinline__ float from_right(float v, float edge) {
 }
 
 // BN: the input carries the producer's BatchNorm + ReLU (always, unless the decoder has a single layer)
+// Sums over the wave of N per-lane values, written to out[0..N) (LDS).  Through LDS in chunks of 16 values instead of six
+// DPP steps per value: the lanes write a chunk as [value][lane], then lane 4v + q reads a quarter of row v (sixteen floats,
+// four 16-byte reads) and two DPP steps join the quarters.  Per value ~2.5 instructions instead of ~8 (+ the DPP hazard
+// no-ops): the DPP form cost the row-streaming kernels 4.3 us of a 10.8 us workgroup lifetime (76 values per lane).
+// A wave's LDS operations execute in order, so the write -> read -> write sequence on `scr` needs no barrier; `scr` is this
+// wave's own kWsumScratch floats.
+constexpr int kWsumLd = 68;                       // row stride: 16-byte aligned, rows 4 banks apart
+constexpr int kWsumScratch = 16 * kWsumLd;
+template <int N>
+__device__ __forceinline__ void wave_sums_lds(const float (&v)[N], float* scr, float* out, int lane) {
+    const int row = lane >> 2, qd = lane & 3;
+#pragma unroll
+    for (int c0 = 0; c0 < N; c0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (c0 + i < N) scr[i * kWsumLd + lane] = v[c0 + i];
+        const float4* p = reinterpret_cast<const float4*>(scr + row * kWsumLd + 4 * qd);   // floats 4 qd + 16 k + {0..3}
+        const float4 a0 = p[0], a1 = p[4], a2 = p[8], a3 = p[12];
+        float t = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) + ((a2.x + a2.y) + (a2.z + a2.w)) +
+                  ((a3.x + a3.y) + (a3.z + a3.w));
+        t += dpp_f<0xB1>(t);        // quad_perm [1,0,3,2]
+        t += dpp_f<0x4E>(t);        // quad_perm [2,3,0,1]
+        if (qd == 0 && c0 + row < N) out[c0 + row] = t;
+    }
+}
+
 // VEC4: output rows are 16-byte aligned and there is one strip (OW % 4 == 0, strips == 1): 16-byte target loads
 template <int CIN, int COUT, int KH, int KW, int HB, bool VEC4, bool BN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_s2_last_fused(S2Last a) {
@@ -86,6 +112,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     static_assert(KH >= 3 && KH <= 4 && KW >= 3 && KW <= 4, "3- or 4-tap stride-2 kernels");
     __shared__ float redf[4 * NRED];
     __shared__ double redd[4 * 2 * COUT];
+    __shared__ __attribute__((aligned(16))) float wscr[4 * kWsumScratch];
 
 #define LF_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x < 384) a.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -407,19 +434,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     }
 
     LF_STAMP(4);
-    // ---- reductions: wave (DPP), workgroup (LDS), then one fp64 atomic per value
+    // ---- reductions: wave (through LDS), workgroup (LDS), then one fp64 atomic per value
+    {
+        float red[NRED];
 #pragma unroll
-    for (int i = 0; i < NACC; i++) {
-        const float s = wave_sum_f(dw[i]);
-        if (lane == 0) redf[wv * NRED + i] = s;
-    }
+        for (int i = 0; i < NACC; i++) red[i] = dw[i];
 #pragma unroll
-    for (int c = 0; c < CIN; c++) {
-        const float s1 = wave_sum_f(d1[c]), s2 = wave_sum_f(d2[c]);
-        if (lane == 0) {
-            redf[wv * NRED + NACC + 2 * c] = s1;
-            redf[wv * NRED + NACC + 2 * c + 1] = s2;
+        for (int c = 0; c < CIN; c++) {
+            red[NACC + 2 * c] = d1[c];
+            red[NACC + 2 * c + 1] = d2[c];
         }
+        wave_sums_lds<NRED>(red, wscr + wv * kWsumScratch, redf + wv * NRED, lane);
     }
 #pragma unroll
     for (int co = 0; co < COUT; co++) {

@@ -1,7 +1,8 @@
-"""Where k_s2_last_fused (kernels_last.h) spends its time: wall-clock stamps (100 MHz) of thread 0 of the first 384
-workgroups at the phase boundaries (CAE_HEAD_DBG=4), read back from the loader's scratch buffer.
+"""Where k_s2_last_fused (kernels_last.h) or k_s2_bwd_rows (kernels_rows.h) spends its time: wall-clock stamps (100 MHz) of
+thread 0 of the first 384 workgroups at the phase boundaries (CAE_HEAD_DBG=4 / 5), read back from the loader's scratch buffer.
 
-    python tools/last_phases.py [batch]
+    python tools/last_phases.py [batch]                 # the fused last layer
+    python tools/last_phases.py [batch] rows [layer]    # the row-streaming backward of decoder layer `layer` (default 4)
 """
 import os
 import sys
@@ -9,13 +10,17 @@ import sys
 import numpy as np
 import torch
 
-os.environ["CAE_HEAD_DBG"] = "4"
+ROWS = len(sys.argv) > 2 and sys.argv[2] == "rows"
+os.environ["CAE_HEAD_DBG"] = "5" if ROWS else "4"
+if ROWS and len(sys.argv) > 3:
+    os.environ["CAE_DBG_LAYER"] = sys.argv[3]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from cae_tools_amd.engine import HipEngine                     # noqa: E402
 from cae_tools_amd.models.model_sizer import create_model_spec  # noqa: E402
 
-PHASES = ["issue loads", "BatchNorm consts + weights", "first row", "remaining rows", "reductions + atomics"]
+PHASES = (["consts + issue loads", "barrier (weights in LDS)", "first row", "remaining rows", "reductions + atomics"] if ROWS else
+          ["issue loads", "BatchNorm consts + weights", "first row", "remaining rows", "reductions + atomics"])
 
 
 def main():
