@@ -492,7 +492,7 @@ bool rows_bwd_ok(const cae_engine* e, const ConvLayer& L) {
 }
 
 void rows_bwd_launch(const ConvLayer& L, S2Rows a, hipStream_t s) {
-    static const int hb42 = env_int("CAE_ROWS_HB42", 2), hb84 = env_int("CAE_ROWS_HB84", 2);   // env: tuning only
+    static const int hb42 = env_int("CAE_ROWS_HB42", 2), hb84 = env_int("CAE_ROWS_HB84", 4);   // env: tuning only
     a.QH = (L.hout + 1) / 2;
     const int lw = (L.wout + 1) / 2 <= 32 ? 32 : 64;
     // short bands with every row's loads issued up front (a wave pays the memory latency once) against tall bands that load one
@@ -503,6 +503,30 @@ void rows_bwd_launch(const ConvLayer& L, S2Rows a, hipStream_t s) {
     } else {
         if (hb84 == 4) rows_go<8, 2, 4, 4, 1>(a, lw, s);
         else rows_go<8, 2, 4, 2, 3>(a, lw, s);
+    }
+}
+
+template <int CIN, int COUT, int HB>
+void rows_fwd_go(S2FwdRows a, int lw, hipStream_t s) {
+    const int hmax = a.QH;
+    a.bands = (hmax + HB - 1) / HB;
+    const int imgs = 64 / lw;
+    a.groups = (a.B + imgs - 1) / imgs;
+    const dim3 grid((unsigned)(a.groups * ((a.bands + 3) / 4)));
+    if (imgs == 1) hipLaunchKernelGGL((k_s2_fwd_rows<CIN, COUT, HB, 1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_s2_fwd_rows<CIN, COUT, HB, 2>), grid, dim3(256), 0, s, a);
+}
+
+void rows_fwd_launch(const ConvLayer& L, S2FwdRows a, hipStream_t s) {
+    static const int hb42 = env_int("CAE_ROWS_FHB42", 2), hb84 = env_int("CAE_ROWS_FHB84", 1);   // env: tuning only
+    a.QH = (L.hout + 1) / 2;
+    const int lw = (L.wout + 1) / 2 <= 32 ? 32 : 64;
+    if (L.cin == 4) {
+        if (hb42 == 4) rows_fwd_go<4, 2, 4>(a, lw, s);
+        else rows_fwd_go<4, 2, 2>(a, lw, s);
+    } else {
+        if (hb84 == 2) rows_fwd_go<8, 4, 2>(a, lw, s);
+        else rows_fwd_go<8, 4, 1>(a, lw, s);
     }
 }
 
@@ -530,7 +554,8 @@ void last_fused_launch(S2Last a, hipStream_t s) {
         const int wmax = a.W > a.QW - 1 ? a.W : a.QW - 1, hmax = a.H > a.QH - 1 ? a.H : a.QH - 1;
         a.strips = (wmax + kLastStripPx - 1) / kLastStripPx;
         // a wave walks a band of HB quad rows (+1 recomputed): taller bands recompute less, shorter ones give more waves
-        int hb = hb_env ? hb_env : ((long long)a.B * a.strips * ((hmax + 7) / 8) >= 1024 ? 8 : 4);
+        // (measured at the benchmark geometry: 2048 waves of 4+1 rows, two per SIMD, beat 1024 of 8+1: 20.4 against 21.8 us)
+        int hb = hb_env ? hb_env : ((long long)a.B * a.strips * ((hmax + 7) / 8) >= 2048 ? 8 : 4);
         if (hb != 8) hb = 4;
         a.bands = (hmax + hb - 1) / hb;
         a.total = a.B * a.strips * a.bands;
@@ -995,6 +1020,23 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             }
         }
         if (last && a.train && last_fused_ok(e, L)) continue;   // forward, loss and backward of this layer: one launch, in launch_backward
+        if (!last && l > 0 && e->dec[l - 1].has_bn && rows_bwd_ok(e, L)) {
+            static const int fwd_rows = env_int("CAE_ROWS_FWD", 1);   // env: A/B measurements only
+            if (fwd_rows) {
+                S2FwdRows f;
+                memset(&f, 0, sizeof f);
+                f.B = B; f.H = L.hin; f.W = L.win; f.OH = L.hout; f.OW = L.wout;
+                f.in = small.p; f.bn_in = bns;
+                f.w = e->params + L.w_off; f.bias = e->params + L.b_off;
+                f.out = ep.out;
+                f.stats = a.train ? ep.stats : nullptr;
+                ProfScope _p(e, a.train ? "s2_convt_fwd" : "s2_convt_eval", (int)l, f4((double)B * (L.in_elems() + L.out_elems())));
+                rows_fwd_launch(L, f, s);
+                if (a.train)
+                    if (int rc = sync_bn_table(e, a, L.bn_index)) return rc;
+                continue;
+            }
+        }
         if (s2_eligible(e, L)) {
             S2Fwd f;
             memset(&f, 0, sizeof f);

@@ -349,3 +349,209 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 }
 
 }  // namespace cae
+
+namespace cae {
+
+// =================================================================================================
+// Forward of the same layers, same walk: a lane per quad column, a wave per band of HB quad rows.  The forward needs no
+// neighbour's results, only input row m0 - 1 again (the inputs are the small side), so the four waves of a workgroup are four
+// independent bands.  Raw output + the BatchNorm sums of this layer (train) or raw output only (eval: stats == nullptr).
+// =================================================================================================
+struct S2FwdRows {
+    int B, H, W, OH, OW;
+    int QH;
+    int bands, groups;
+    const float* in;         // (B, CIN, H, W) raw output of the producer
+    BnDesc bn_in;            // BN_BATCH / BN_RUNNING of the producer
+    const float* w;          // (CIN, COUT, 3, 3)
+    const float* bias;       // (COUT)
+    float* out;              // (B, COUT, OH, OW) raw output
+    double* stats;           // [kStatShards][COUT][4] slots 0, 1, or nullptr
+};
+
+template <int CIN, int COUT, int HB, int IMGS>
+__global__ void __launch_bounds__(256) k_s2_fwd_rows(S2FwdRows a) {
+    constexpr int KH = 3, KW = 3;
+    constexpr int LW = 64 / IMGS;
+    constexpr int NRED = 2 * COUT;
+    static_assert(CIN <= 8, "one lane per (channel, shard) in the BatchNorm prologue");
+    __shared__ float redf[4 * NRED];
+    __shared__ __attribute__((aligned(16))) float wscr[4 * kWsumScratch];
+    __shared__ __attribute__((aligned(16))) float wl[CIN * COUT * 12];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane / LW, n = lane - sub * LW;
+    const unsigned HW = a.H * a.W, OHW = a.OH * a.OW;
+    const int wg_bands = (a.bands + 3) / 4;
+    const int grp = blockIdx.x / wg_bands, bg0 = blockIdx.x - grp * wg_bands;
+    const int band = bg0 * 4 + wv;
+    const bool band_ok = band < a.bands;
+    const int m0 = band * HB;
+    const int b = grp * IMGS + sub;
+    const bool img_ok = b < a.B;
+    const int bc = img_ok ? b : a.B - 1;
+
+    // ---- BatchNorm of the producer: batch statistics (train; workgroup 0 saves them and moves the running statistics) or
+    // running statistics (eval).  Lanes 8 c + shard read the shards of channel c; three DPP steps; lane 8 c hands them out.
+    float4 ki[CIN];
+    {
+        const bool batch = a.bn_in.mode == BN_BATCH;
+        double sa = 0.0, sb = 0.0;
+        if (batch && lane < 8 * CIN) {
+            const double2 t = *reinterpret_cast<const double2*>(a.bn_in.stats + ((size_t)(lane & 7) * CIN + (lane >> 3)) * 4);
+            sa = t.x;
+            sb = t.y;
+        }
+        float gam[CIN], bet[CIN], rmn[CIN], rvr[CIN];
+#pragma unroll
+        for (int c = 0; c < CIN; c++) {
+            gam[c] = a.bn_in.gamma[c];
+            bet[c] = a.bn_in.beta[c];
+            rmn[c] = a.bn_in.rmean[c];
+            rvr[c] = a.bn_in.rvar[c];
+        }
+        for (int i = tid; i < CIN * COUT * 12; i += 256) {
+            const int cc = i / 12, t = i - cc * 12;
+            wl[i] = t < 9 ? a.w[cc * 9 + t] : 0.f;
+        }
+        sa += dpp_d<0xB1>(sa); sb += dpp_d<0xB1>(sb);
+        sa += dpp_d<0x4E>(sa); sb += dpp_d<0x4E>(sb);
+        sa += dpp_d<0x141>(sa); sb += dpp_d<0x141>(sb);
+        const long long ba = __builtin_bit_cast(long long, sa), bb = __builtin_bit_cast(long long, sb);
+#pragma unroll
+        for (int c = 0; c < CIN; c++) {
+            float mean, invstd;
+            if (batch) {
+                const int lo1 = __builtin_amdgcn_readlane((int)ba, 8 * c), hi1 = __builtin_amdgcn_readlane((int)(ba >> 32), 8 * c);
+                const int lo2 = __builtin_amdgcn_readlane((int)bb, 8 * c), hi2 = __builtin_amdgcn_readlane((int)(bb >> 32), 8 * c);
+                const double s1 = __builtin_bit_cast(double, ((long long)hi1 << 32) | (unsigned)lo1);
+                const double s2 = __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned)lo2);
+                const double mu = s1 * a.bn_in.inv_count;
+                double var = s2 * a.bn_in.inv_count - mu * mu;
+                var = var < 0.0 ? 0.0 : var;
+                mean = (float)mu;
+                invstd = 1.0f / sqrtf((float)(var + (double)a.bn_in.eps));
+                if (blockIdx.x == 0 && tid == 0 && a.bn_in.update) {
+                    a.bn_in.saved[2 * c] = mean;
+                    a.bn_in.saved[2 * c + 1] = invstd;
+                    a.bn_in.rmean[c] = (1.f - a.bn_in.momentum) * rmn[c] + a.bn_in.momentum * mean;
+                    a.bn_in.rvar[c] = (1.f - a.bn_in.momentum) * rvr[c] + a.bn_in.momentum * (float)(var * a.bn_in.unbias);
+                }
+            } else {
+                mean = uniform_f(rmn[c]);
+                invstd = 1.0f / sqrtf(uniform_f(rvr[c]) + a.bn_in.eps);
+            }
+            ki[c] = make_float4(mean, uniform_f(gam[c]) * invstd, uniform_f(bet[c]), invstd);
+        }
+    }
+    float bk[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; co++) bk[co] = a.bias[co];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- every input row of the band up front: rows m0 - 1 .. m0 + HB - 1, this lane's column
+    float rin[HB + 1][CIN];
+    {
+        const float* ib = a.in + (size_t)bc * CIN * HW;
+        const int xc = min(n, a.W - 1);
+#pragma unroll
+        for (int r = 0; r <= HB; r++) {
+            const unsigned ro = (unsigned)min(max(m0 - 1 + r, 0), a.H - 1) * a.W;
+#pragma unroll
+            for (int c = 0; c < CIN; c++) rin[r][c] = ib[c * HW + ro + xc];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int co = 0; co < COUT; co++) bk[co] = uniform_f(bk[co]);
+    __syncthreads();         // wl is complete
+
+    auto activate = [&](int r, int c, float (&act)[2]) {
+        const int y = m0 - 1 + r;
+        const float v = fmaxf(0.f, fmaf(rin[r][c] - ki[c].x, ki[c].y, ki[c].z));
+        act[1] = (y >= 0 && y < a.H && n < a.W) ? v : 0.f;
+        const float left = from_left(act[1], 0.f);
+        act[0] = n == 0 ? 0.f : left;
+    };
+    float actP[CIN][2];
+#pragma unroll
+    for (int c = 0; c < CIN; c++) activate(0, c, actP[c]);
+    float s1[COUT], s2[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; co++) s1[co] = s2[co] = 0.f;
+    const bool pair_ok = 2 * n + 1 < a.OW;
+    float* ob = a.out + (size_t)bc * COUT * OHW;
+
+    static_for<HB>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        const int m = m0 + r;
+        if (m < a.QH && band_ok) {
+            float actN[CIN][2];
+#pragma unroll
+            for (int c = 0; c < CIN; c++) activate(r + 1, c, actN[c]);
+            int wofs = 0;
+            asm volatile("" : "+v"(wofs));       // keeps the weight reads of different rows apart (kernels_rows.h, backward)
+#pragma unroll
+            for (int co = 0; co < COUT; co++) {
+                float acc[2][2] = {{bk[co], bk[co]}, {bk[co], bk[co]}};
+#pragma unroll
+                for (int c = 0; c < CIN; c++) {
+                    float wc[12];
+                    {
+                        const float4* wq = reinterpret_cast<const float4*>(&wl[(c * COUT + co) * 12 + wofs]);
+                        const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2];
+                        wc[0] = w0.x; wc[1] = w0.y; wc[2] = w0.z; wc[3] = w0.w; wc[4] = w1.x; wc[5] = w1.y; wc[6] = w1.z; wc[7] = w1.w;
+                        wc[8] = w2.x; wc[9] = w2.y; wc[10] = w2.z; wc[11] = w2.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int i = 0; i < 2; i++) {
+                            const float av = j ? actP[c][1 - i] : actN[c][1 - i];
+#pragma unroll
+                            for (int py = 0; py < 2; py++)
+#pragma unroll
+                                for (int px = 0; px < 2; px++)
+                                    if (py + 2 * j < KH && px + 2 * i < KW)
+                                        acc[py][px] = fmaf(av, wc[(py + 2 * j) * KW + px + 2 * i], acc[py][px]);
+                        }
+                }
+#pragma unroll
+                for (int py = 0; py < 2; py++) {
+                    const int oy = 2 * m + py;
+                    const bool ok0 = img_ok && oy < a.OH && 2 * n < a.OW, ok1 = ok0 && pair_ok;
+                    float* op = ob + co * OHW + (unsigned)min(oy, a.OH - 1) * a.OW + min(2 * n, a.OW - 1);
+                    if (ok1) *reinterpret_cast<float2*>(op) = make_float2(acc[py][0], acc[py][1]);
+                    else if (ok0) op[0] = acc[py][0];
+                    const float v0 = ok0 ? acc[py][0] : 0.f, v1 = ok1 ? acc[py][1] : 0.f;
+                    s1[co] += v0 + v1;
+                    s2[co] = fmaf(v0, v0, fmaf(v1, v1, s2[co]));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CIN; c++) {
+                actP[c][0] = actN[c][0];
+                actP[c][1] = actN[c][1];
+            }
+        }
+    });
+    if (!a.stats) return;
+    {
+        float red[NRED];
+#pragma unroll
+        for (int co = 0; co < COUT; co++) {
+            red[2 * co] = s1[co];
+            red[2 * co + 1] = s2[co];
+        }
+        wave_sums_lds<NRED>(red, wscr + wv * kWsumScratch, redf + wv * NRED, lane);
+    }
+    __syncthreads();
+    if (tid < NRED) {
+        const double s = (double)redf[tid] + (double)redf[NRED + tid] + (double)redf[2 * NRED + tid] + (double)redf[3 * NRED + tid];
+        atomicAdd(&a.stats[((size_t)(blockIdx.x & (kStatShards - 1)) * COUT + (tid >> 1)) * 4 + (tid & 1)], s);
+    }
+}
+
+}  // namespace cae
