@@ -206,6 +206,60 @@ def test_adam_step_by_step(name):
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
+def test_adam_step_no_further_from_fp64_than_the_reference(name):
+    """The step-by-step check above bounds the update in units of lr; this one says what those units hide.  Before every step
+    the engine, the fp32 oracle (the reference's arithmetic) and an fp64 oracle start from the same weights, running statistics
+    and Adam moments; all three take the step.  Per tensor, the engine's update may be no further (max norm) from the fp64
+    update than 3x the fp32 reference's own update is, plus 1e-3 of lr: where Adam's m / (sqrt(v) + eps) amplifies a gradient
+    rounding error, it amplifies the reference's just as much."""
+    from oracle import cae_oracle as orc_mod
+    case = GoldenCase(name)
+    lr = case.meta["lr"]
+    eng = _engine(case)
+    _dataset(eng, case)
+    b, b2 = case.meta["batch"], case.x2.shape[0]
+    orc = _oracle(case)
+    batches = [(torch.from_numpy(case.x), torch.from_numpy(case.t)), (torch.from_numpy(case.x2), torch.from_numpy(case.t2))]
+    noisy = bn_bias_keys(case.spec)
+    worst = 0.0
+    for s in range(case.meta["nsteps"]):
+        before = orc.state()
+        moments = _oracle_moments(orc)
+        enc = {k[4:]: v for k, v in before.items() if k.startswith("enc/")}
+        dec = {k[4:]: v for k, v in before.items() if k.startswith("dec/")}
+        eng.load_state(enc, dec)
+        eng.load_optimizer_state(moments, s)
+        # the same state in fp64
+        to64 = lambda sd: {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        o64 = orc_mod.OracleModel(case.spec, to64(enc), to64(dec), lr=lr, weight_decay=case.meta["weight_decay"])
+        for side, group in (("enc/", o64.enc), ("dec/", o64.dec)):
+            for k, p64 in group.items():
+                if side + k in moments:
+                    (m, v) = moments[side + k]
+                    o64.optim.state[p64] = {"step": torch.tensor(float(s)), "exp_avg": m.double().clone(), "exp_avg_sq": v.double().clone()}
+        (xb, tb) = batches[s % 2]
+        orc.train_step(xb, tb)
+        o64.train_step(xb.double(), tb.double())
+        eng.train_step(0, None, 0 if s % 2 == 0 else b, b if s % 2 == 0 else b2)
+        (after32, after64) = (orc.state(), o64.state())
+        (e2, d2) = eng.export_state()
+        for side, sd in (("enc/", e2), ("dec/", d2)):
+            for k, v in sd.items():
+                key = side + k
+                if k.endswith("num_batches_tracked") or "running_" in k or key in noisy:
+                    continue
+                b0 = before[key].numpy().astype(np.float64)
+                d64 = after64[key].numpy() - b0
+                d32 = after32[key].numpy().astype(np.float64) - b0
+                dh = v.numpy().astype(np.float64) - b0
+                (err_ref, err_hip) = (float(np.abs(d32 - d64).max()), float(np.abs(dh - d64).max()))
+                worst = max(worst, err_hip / (3.0 * err_ref + 1e-3 * lr))
+                assert err_hip <= 3.0 * err_ref + 1e-3 * lr, \
+                    f"step {s} {key}: |hip - fp64| = {err_hip:.3e}, the reference's own {err_ref:.3e} (lr {lr:g})"
+    print(f"{name}: worst ratio to the bound {worst:.2f}")
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
 def test_adam_steps_free_running(name):
     """4 steps from the initial state without re-synchronisation, against the reference's stored
     trajectory (golden steps/*): losses tight, 99 % of every parameter tensor within a tenth of
