@@ -116,3 +116,51 @@ def test_linear_two_shards_sum_to_the_full_batch_step():
     ls = halves.read_losses(4, 2)
     (lo, hi) = shard_bounds(n, 2, 0)
     assert (ls[0] * (hi - lo) + ls[1] * (n - hi + lo)) / n == pytest.approx(full.read_losses(1, 1)[0], rel=1e-3)
+
+
+def _grad_scale_check(eng, n, rows):
+    """The gradient a rank hands to the all-reduce: forward_backward(shard, global_batch = n) must be exactly the shard's own
+    gradient times shard / n (Adam's early steps are almost blind to a wrong scale, so the parameter comparisons above cannot
+    see it).  Same shard, same weights, same dropout / reparameterisation step: only the scale differs."""
+    step = getattr(eng, "steps", 0)
+    g_own = eng.forward_backward(0, None, 0, rows, slot=10).clone()
+    if hasattr(eng, "set_step"):
+        eng.set_step(step)
+    g_dp = eng.forward_backward(0, None, 0, rows, slot=11, global_batch=n).clone()
+    want = g_own * (rows / n)
+    scale = float(want.abs().max())
+    assert scale > 0
+    assert float((g_dp - want).abs().max()) <= 1e-5 * scale
+
+
+def test_unet_shard_gradient_carries_local_over_global(dist1):
+    from test_unet_hip_parity import _engine
+    from unet_helpers import UnetCase
+    c = UnetCase("u_k4_b3")
+    (x, t, m) = c.step_batch(0)
+    eng = _engine(c)
+    eng.set_dataset(0, x, t, m)
+    _grad_scale_check(eng, 7, x.shape[0])
+
+
+def test_vae_shard_gradient_carries_local_over_global(dist1):
+    from test_vae_hip_parity import _engine, _setup
+    (fc, latent, B) = (12, 4, 3)
+    (spec, enc, dec, x, t) = _setup((12, 12), (176, 176), fc, latent, B, seed=21)
+    eng = _engine(spec, enc, dec, fc, latent, B, lr=1e-3, seed=4)
+    eng.set_dataset(0, x, t)
+    _grad_scale_check(eng, 8, B)
+
+
+def test_linear_shard_gradients_sum_to_the_full_batch_gradient():
+    """no batch statistics in this model: the two shards' scaled gradients add up to the full-batch gradient itself"""
+    from cae_tools_amd.dp import shard_bounds
+    n = 7
+    eng = _linear(n)()
+    full = eng.forward_backward(0, None, 0, n, slot=20).clone()
+    total = torch.zeros_like(full)
+    for r in range(2):
+        (lo, hi) = shard_bounds(n, 2, r)
+        total += eng.forward_backward(0, None, lo, hi - lo, slot=21 + r, global_batch=n)
+    assert float((total - full).abs().max()) <= 1e-5 * float(full.abs().max())
+    _grad_scale_check(eng, n, 3)
