@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     const bool last_band = band == a.bands - 1, last_strip = strip == a.strips - 1;
     const int n0 = strip * kLastStripPx + 2 * lane;      // first of the lane's two quad columns = its first pixel column
     const bool multi = a.strips > 1;
+    const bool all_cols = VEC4 && 256 <= a.OW;           // uniform: every lane's four output columns are inside the map
 
     // ---- loads, in the order their consumers can use them.  The wave's memory counter retires in issue order, so whatever a
     // value's consumer waits for, it waits for everything issued before it: the small dependent reads (cursor -> permutation
@@ -339,18 +340,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 #pragma unroll
                         for (int px = 0; px < 2; px++) {
                             const int ox = 2 * (n0 + q) + px;
-                            const bool valid = rowok && ox < a.OW;
+                            const bool valid = rowok && (all_cols || ox < a.OW);
                             const float yh = sigmoid_fast(acc[q][py][px]);
                             // an output outside the map has no error: d = 0 makes its loss term and its gradient vanish
                             const float d = valid ? yh - tv[2 * q + px] : 0.f;
                             const float gv = (2.0f * d * a.inv_count) * (yh * (1.0f - yh));
                             g[co][q][py][px] = gv;
                             // a quad column is counted by the strip that owns it: the last lane's second quad is the next strip's
-                            // (selects, not branches: a wave runs alone on its SIMD and every exec-mask branch is a bubble)
-                            const bool own = own_row && (VEC4 || q == 0 || lane < 63 || last_strip);   // VEC4: one strip, owns all it computes
-                            const float dl = own ? d : 0.f;
-                            ls[co] = fmaf(dl, dl, ls[co]);
-                            gs[co] += own ? gv : 0.f;
+                            // (selects, not branches: a wave runs alone on its SIMD and every exec-mask branch is a bubble);
+                            // with one strip (VEC4) ownership is the row's, a uniform branch
+                            if constexpr (VEC4) {
+                                if (own_row) { ls[co] = fmaf(d, d, ls[co]); gs[co] += gv; }
+                            } else {
+                                const bool own = own_row && (q == 0 || lane < 63 || last_strip);
+                                const float dl = own ? d : 0.f;
+                                ls[co] = fmaf(dl, dl, ls[co]);
+                                gs[co] += own ? gv : 0.f;
+                            }
                         }
                 }
             }

@@ -78,60 +78,37 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     const bool has_below = NB > 1 && bsel + 1 < NB && band + 1 < a.bands;   // the band below is in this workgroup
     const int nrows = has_below ? HB : NR;
 
-    // ---- constants: BatchNorm of this layer's output (backward form) and of the producer (saved statistics), in registers
-    // {mean, k1, k2, k3} per output channel: lanes 8 c + shard read the shards of channel c (one 16-byte load), three DPP steps
+    // ---- small reads first (the memory counter retires in issue order: kernels_last.h), the band's rows behind them, the
+    // arithmetic on the small reads behind that.  BatchNorm of this layer's output (backward form {mean, k1, k2, k3}) and of the
+    // producer (saved statistics): lanes 8 c + shard read the shards of channel c (one 16-byte load), three DPP steps below.
     float4 ko[COUT], ki[CT];
-    {
-        double sa = 0.0, sb = 0.0;
-        if (lane < 8 * COUT) {
-            const double2 t = *reinterpret_cast<const double2*>(a.bn_out.stats + ((size_t)(lane & 7) * COUT + (lane >> 3)) * 4 + 2);
-            sa = t.x;
-            sb = t.y;
-        }
-        float mean_o[COUT], istd_o[COUT], gam_o[COUT];
-#pragma unroll
-        for (int co = 0; co < COUT; co++) {
-            mean_o[co] = a.bn_out.saved[2 * co];
-            istd_o[co] = a.bn_out.saved[2 * co + 1];
-            gam_o[co] = a.bn_out.gamma[co];
-        }
-        float mean_i[CT], istd_i[CT], gam_i[CT], bet_i[CT];
-#pragma unroll
-        for (int c = 0; c < CT; c++) {
-            mean_i[c] = a.bn_in.saved[2 * (c0 + c)];
-            istd_i[c] = a.bn_in.saved[2 * (c0 + c) + 1];
-            gam_i[c] = a.bn_in.gamma[c0 + c];
-            bet_i[c] = a.bn_in.beta[c0 + c];
-        }
-        sa += dpp_d<0xB1>(sa); sb += dpp_d<0xB1>(sb);
-        sa += dpp_d<0x4E>(sa); sb += dpp_d<0x4E>(sb);
-        sa += dpp_d<0x141>(sa); sb += dpp_d<0x141>(sb);
-        const long long ba = __builtin_bit_cast(long long, sa), bb = __builtin_bit_cast(long long, sb);
-#pragma unroll
-        for (int co = 0; co < COUT; co++) {
-            const int lo1 = __builtin_amdgcn_readlane((int)ba, 8 * co), hi1 = __builtin_amdgcn_readlane((int)(ba >> 32), 8 * co);
-            const int lo2 = __builtin_amdgcn_readlane((int)bb, 8 * co), hi2 = __builtin_amdgcn_readlane((int)(bb >> 32), 8 * co);
-            const double dbeta = __builtin_bit_cast(double, ((long long)hi1 << 32) | (unsigned)lo1);
-            const double dgamma = __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned)lo2);
-            const float mean = uniform_f(mean_o[co]), invstd = uniform_f(istd_o[co]);
-            const float scale = uniform_f(gam_o[co]) * invstd;
-            // bn_consts, BN_BWD: gy = k1 g - k2 - (y - mean) k3
-            ko[co] = make_float4(mean, scale, (float)((double)scale * dbeta * a.bn_out.inv_count),
-                                 (float)((double)scale * (double)invstd * dgamma * a.bn_out.inv_count));
-            if (blockIdx.x == 0 && tid == 0 && a.bg.stats) {   // this layer's BatchNorm parameter gradients
-                a.bg.beta_acc[co] = dbeta * a.bg.scale;
-                a.bg.gamma_acc[co] = dgamma * a.bg.scale;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < CT; c++) {
-            const float invstd = uniform_f(istd_i[c]);
-            ki[c] = make_float4(uniform_f(mean_i[c]), uniform_f(gam_i[c]) * invstd, uniform_f(bet_i[c]), invstd);
-        }
+    double sa = 0.0, sb = 0.0;
+    if (lane < 8 * COUT) {
+        const double2 t = *reinterpret_cast<const double2*>(a.bn_out.stats + ((size_t)(lane & 7) * COUT + (lane >> 3)) * 4 + 2);
+        sa = t.x;
+        sb = t.y;
     }
-    for (int i = tid; i < CIN * COUT * 12; i += 256) {
-        const int cc = i / 12, t = i - cc * 12;
-        wl[i] = t < 9 ? a.w[cc * 9 + t] : 0.f;
+    float mean_o[COUT], istd_o[COUT], gam_o[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; co++) {
+        mean_o[co] = a.bn_out.saved[2 * co];
+        istd_o[co] = a.bn_out.saved[2 * co + 1];
+        gam_o[co] = a.bn_out.gamma[co];
+    }
+    float mean_i[CT], istd_i[CT], gam_i[CT], bet_i[CT];
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+        mean_i[c] = a.bn_in.saved[2 * (c0 + c)];
+        istd_i[c] = a.bn_in.saved[2 * (c0 + c) + 1];
+        gam_i[c] = a.bn_in.gamma[c0 + c];
+        bet_i[c] = a.bn_in.beta[c0 + c];
+    }
+    constexpr int NWL = (CIN * COUT * 12 + 255) / 256;      // weight-image elements a thread stages
+    float wreg[NWL];
+#pragma unroll
+    for (int u = 0; u < NWL; u++) {
+        const int i = min(tid + 256 * u, CIN * COUT * 12 - 1), cc = i / 12, t = i - cc * 12;
+        wreg[u] = a.w[cc * 9 + min(t, 8)];
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -174,6 +151,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     });
     __builtin_amdgcn_sched_barrier(0);
     RW_STAMP(1);
+    {   // the constants, now that the rows are on their way
+        sa += dpp_d<0xB1>(sa); sb += dpp_d<0xB1>(sb);
+        sa += dpp_d<0x4E>(sa); sb += dpp_d<0x4E>(sb);
+        sa += dpp_d<0x141>(sa); sb += dpp_d<0x141>(sb);
+        const long long ba = __builtin_bit_cast(long long, sa), bb = __builtin_bit_cast(long long, sb);
+#pragma unroll
+        for (int co = 0; co < COUT; co++) {
+            const int lo1 = __builtin_amdgcn_readlane((int)ba, 8 * co), hi1 = __builtin_amdgcn_readlane((int)(ba >> 32), 8 * co);
+            const int lo2 = __builtin_amdgcn_readlane((int)bb, 8 * co), hi2 = __builtin_amdgcn_readlane((int)(bb >> 32), 8 * co);
+            const double dbeta = __builtin_bit_cast(double, ((long long)hi1 << 32) | (unsigned)lo1);
+            const double dgamma = __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned)lo2);
+            const float mean = uniform_f(mean_o[co]), invstd = uniform_f(istd_o[co]);
+            const float scale = uniform_f(gam_o[co]) * invstd;
+            // bn_consts, BN_BWD: gy = k1 g - k2 - (y - mean) k3
+            ko[co] = make_float4(mean, scale, (float)((double)scale * dbeta * a.bn_out.inv_count),
+                                 (float)((double)scale * (double)invstd * dgamma * a.bn_out.inv_count));
+            if (blockIdx.x == 0 && tid == 0 && a.bg.stats) {   // this layer's BatchNorm parameter gradients
+                a.bg.beta_acc[co] = dbeta * a.bg.scale;
+                a.bg.gamma_acc[co] = dgamma * a.bg.scale;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            const float invstd = uniform_f(istd_i[c]);
+            ki[c] = make_float4(uniform_f(mean_i[c]), uniform_f(gam_i[c]) * invstd, uniform_f(bet_i[c]), invstd);
+        }
+#pragma unroll
+        for (int u = 0; u < NWL; u++) {
+            const int i = tid + 256 * u;
+            if (i < CIN * COUT * 12) wl[i] = (i % 12) < 9 ? wreg[u] : 0.f;
+        }
+    }
     __syncthreads();         // wl is complete
     RW_STAMP(2);
 
@@ -392,29 +401,52 @@ __global__ void __launch_bounds__(256) k_s2_fwd_rows(S2FwdRows a) {
     const bool img_ok = b < a.B;
     const int bc = img_ok ? b : a.B - 1;
 
-    // ---- BatchNorm of the producer: batch statistics (train; workgroup 0 saves them and moves the running statistics) or
-    // running statistics (eval).  Lanes 8 c + shard read the shards of channel c; three DPP steps; lane 8 c hands them out.
+    // ---- small reads first, the band's input rows behind them, the arithmetic on the small reads behind that (kernels_last.h).
+    // BatchNorm of the producer: batch statistics (train; workgroup 0 saves them and moves the running statistics) or running
+    // statistics (eval).  Lanes 8 c + shard read the shards of channel c; three DPP steps; lane 8 c hands them out.
     float4 ki[CIN];
-    {
-        const bool batch = a.bn_in.mode == BN_BATCH;
-        double sa = 0.0, sb = 0.0;
-        if (batch && lane < 8 * CIN) {
-            const double2 t = *reinterpret_cast<const double2*>(a.bn_in.stats + ((size_t)(lane & 7) * CIN + (lane >> 3)) * 4);
-            sa = t.x;
-            sb = t.y;
-        }
-        float gam[CIN], bet[CIN], rmn[CIN], rvr[CIN];
+    const bool batch = a.bn_in.mode == BN_BATCH;
+    double sa = 0.0, sb = 0.0;
+    if (batch && lane < 8 * CIN) {
+        const double2 t = *reinterpret_cast<const double2*>(a.bn_in.stats + ((size_t)(lane & 7) * CIN + (lane >> 3)) * 4);
+        sa = t.x;
+        sb = t.y;
+    }
+    float gam[CIN], bet[CIN], rmn[CIN], rvr[CIN];
 #pragma unroll
-        for (int c = 0; c < CIN; c++) {
-            gam[c] = a.bn_in.gamma[c];
-            bet[c] = a.bn_in.beta[c];
-            rmn[c] = a.bn_in.rmean[c];
-            rvr[c] = a.bn_in.rvar[c];
+    for (int c = 0; c < CIN; c++) {
+        gam[c] = a.bn_in.gamma[c];
+        bet[c] = a.bn_in.beta[c];
+        rmn[c] = a.bn_in.rmean[c];
+        rvr[c] = a.bn_in.rvar[c];
+    }
+    constexpr int NWL = (CIN * COUT * 12 + 255) / 256;
+    float wreg[NWL];
+#pragma unroll
+    for (int u = 0; u < NWL; u++) {
+        const int i = min(tid + 256 * u, CIN * COUT * 12 - 1), cc = i / 12, t = i - cc * 12;
+        wreg[u] = a.w[cc * 9 + min(t, 8)];
+    }
+    float bk[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; co++) bk[co] = a.bias[co];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- every input row of the band up front: rows m0 - 1 .. m0 + HB - 1, this lane's column
+    float rin[HB + 1][CIN];
+    {
+        const float* ib = a.in + (size_t)bc * CIN * HW;
+        const int xc = min(n, a.W - 1);
+#pragma unroll
+        for (int r = 0; r <= HB; r++) {
+            const unsigned ro = (unsigned)min(max(m0 - 1 + r, 0), a.H - 1) * a.W;
+#pragma unroll
+            for (int c = 0; c < CIN; c++) rin[r][c] = ib[c * HW + ro + xc];
         }
-        for (int i = tid; i < CIN * COUT * 12; i += 256) {
-            const int cc = i / 12, t = i - cc * 12;
-            wl[i] = t < 9 ? a.w[cc * 9 + t] : 0.f;
-        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
         sa += dpp_d<0xB1>(sa); sb += dpp_d<0xB1>(sb);
         sa += dpp_d<0x4E>(sa); sb += dpp_d<0x4E>(sb);
         sa += dpp_d<0x141>(sa); sb += dpp_d<0x141>(sb);
@@ -444,28 +476,14 @@ __global__ void __launch_bounds__(256) k_s2_fwd_rows(S2FwdRows a) {
             }
             ki[c] = make_float4(mean, uniform_f(gam[c]) * invstd, uniform_f(bet[c]), invstd);
         }
-    }
-    float bk[COUT];
 #pragma unroll
-    for (int co = 0; co < COUT; co++) bk[co] = a.bias[co];
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- every input row of the band up front: rows m0 - 1 .. m0 + HB - 1, this lane's column
-    float rin[HB + 1][CIN];
-    {
-        const float* ib = a.in + (size_t)bc * CIN * HW;
-        const int xc = min(n, a.W - 1);
-#pragma unroll
-        for (int r = 0; r <= HB; r++) {
-            const unsigned ro = (unsigned)min(max(m0 - 1 + r, 0), a.H - 1) * a.W;
-#pragma unroll
-            for (int c = 0; c < CIN; c++) rin[r][c] = ib[c * HW + ro + xc];
+        for (int u = 0; u < NWL; u++) {
+            const int i = tid + 256 * u;
+            if (i < CIN * COUT * 12) wl[i] = (i % 12) < 9 ? wreg[u] : 0.f;
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int co = 0; co < COUT; co++) bk[co] = uniform_f(bk[co]);
+        for (int co = 0; co < COUT; co++) bk[co] = uniform_f(bk[co]);
+    }
     __syncthreads();         // wl is complete
 
     auto activate = [&](int r, int c, float (&act)[2]) {
