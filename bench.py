@@ -217,8 +217,12 @@ def main():
     # parallelism): a global batch is 64 * world consecutive rows of the permutation, rank r takes rows [64 r, 64 r + 64)
     ds_train = circle_data(N_TRAIN, 1234)
     x, t = packed(ds_train)
+    # the frozen shuffle, materialised once as ConvAEModel.train does (the reference stacks its shuffled batches once and
+    # reuses the list every epoch, conv_ae_model.py:315-325): batches are contiguous rows, no permutation look-up in the step
+    order = torch.as_tensor(np.random.default_rng(99).permutation(N_TRAIN), device=device)
+    (x, t) = (x.index_select(0, order), t.index_select(0, order))
     eng.set_dataset(0, x, t)
-    perm = eng.upload_perm(np.random.default_rng(99).permutation(N_TRAIN))
+    perm = None
     global_batch = BATCH * world
     steps_per_epoch = N_TRAIN // global_batch
     dp_graph = None

@@ -222,10 +222,16 @@ class ConvAEModel(BaseModel):
         eng = self._get_engine(-(-int(self.batch_size) // world))   # a rank's share of a global batch
         eng.set_hyper(lr=self.lr, weight_decay=self.weight_decay)
         eng.reset_optimizer()      # torch.optim.Adam is re-created on every train() (:310)
-        eng.set_dataset(_eng.TRAIN, train_ds.device_inputs(), train_ds.device_outputs())
-        eng.set_dataset(_eng.TEST, test_ds.device_inputs(), test_ds.device_outputs())
-        train_idx = eng.upload_perm(train_perm)
-        test_idx = eng.upload_perm(test_perm)
+        # The reference stacks its shuffled batches ONCE and reuses that list every epoch (:315-325).  The same here: both data
+        # sets are laid out in batch order once (a device gather), so a batch is a contiguous run of rows and the kernels
+        # need no permutation look-up in front of their first load (one dependent memory round trip less per gathering
+        # kernel: the encoder's head, the last layer's targets, the first conv's weight gradient).
+        def frozen(ds, perm):
+            idx = torch.as_tensor(np.asarray(perm, dtype=np.int64), device=ds.device_inputs().device)
+            return ds.device_inputs().index_select(0, idx), ds.device_outputs().index_select(0, idx)
+        eng.set_dataset(_eng.TRAIN, *frozen(train_ds, train_perm))
+        eng.set_dataset(_eng.TEST, *frozen(test_ds, test_perm))
+        train_idx = test_idx = None
         par = None
         if dist is not None:
             par = _dp.DataParallel(eng, dist, sync_bn=self.sync_bn)
