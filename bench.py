@@ -286,9 +286,10 @@ def main():
                        "global_batch": BATCH * world, "n_train": N_TRAIN, "params": 112271,
                        "parallelism": (f"dp{world}" + ("+syncbn" if args.sync_bn else "")) if dist is not None else "single",
                        "dp_collectives": None if dist is None else
-                       ("RCCL all-reduce of 2 gradient buckets, " +
-                        ("first one on a second stream beside the tail of backward" if eng.dp_overlap and not args.sync_bn
-                         else "both on the main stream after backward") +
+                       (("RCCL all-reduce of 2 gradient buckets, first one on a second stream beside the tail of backward"
+                         if eng.dp_overlap and not args.sync_bn else
+                         "one RCCL all-reduce of the whole gradient arena on the main stream after backward" if not args.sync_bn else
+                         "RCCL all-reduce of 2 gradient buckets and of every BatchNorm sum table on the main stream") +
                         (", captured in the step graph" if dp_graph else ", plain launches")),
                        "dp_calibration_us_per_step": None if dist is None else
                        {k: round(v * 1e6, 1) for k, v in dp_times.items()}},

@@ -846,8 +846,12 @@ bool dp_overlap(const cae_engine* e, const StepArgs& a) {
     return (forced >= 0 ? forced != 0 : e->dp_overlap) && !a.dp_sync;
 }
 
+// Without the overlap (and without SyncBN) there is nothing to gain from two buckets: ONE narrowing launch and ONE all-reduce
+// of the whole gradient arena after backward - one collective latency per step instead of two.
+bool dp_single_collective(const cae_engine* e, const StepArgs& a) { return !dp_overlap(e, a) && !a.dp_sync; }
+
 int dp_first_bucket(cae_engine* e, const StepArgs& a) {
-    if (!a.dp) return CAE_OK;
+    if (!a.dp || dp_single_collective(e, a)) return CAE_OK;
     const int64_t lo = e->bucket_split, hi = e->n_param;
     const bool overlap = dp_overlap(e, a);
     hipStream_t on = overlap ? e->comm_stream : e->stream;
@@ -868,7 +872,7 @@ int dp_first_bucket(cae_engine* e, const StepArgs& a) {
 // after the last backward kernel: second bucket, join, Adam from the reduced fp32 gradients
 int dp_finish_step(cae_engine* e, const StepArgs& a) {
     hipStream_t s = e->stream;
-    const int64_t lo = 0, hi = e->bucket_split;
+    const int64_t lo = 0, hi = dp_single_collective(e, a) ? e->n_param : e->bucket_split;
     {
         ProfScope _p(e, "dp_narrow_bucket1", 0, 12.0 * (hi - lo));
         hipLaunchKernelGGL(k_narrow_range, dim3(grid1(hi - lo > 0 ? hi - lo : 1)), dim3(256), 0, s, (long long)lo, (long long)hi,

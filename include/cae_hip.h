@@ -170,8 +170,8 @@ int cae_forward_backward_sync(cae_engine* e, int which, const int32_t* perm_dev,
  *   it (2 per BatchNorm layer per step), which makes N ranks x batch/N reproduce the reference's single-device batch-N
  *   step (encoder.py:45, decoder.py:47 normalise over the whole batch); sync_bn = 0: per-rank statistics (what torch's
  *   DistributedDataParallel does without SyncBatchNorm), for throughput.
- * cae_dp_set_overlap: 1 (default) = the first bucket leaves on the second stream as described; 0 = both buckets on the
- *   main stream after backward (no cross-stream edges).  Same arithmetic, same results; which is faster depends on the
+ * cae_dp_set_overlap: 1 (default) = the first bucket leaves on the second stream as described; 0 = ONE all-reduce of the
+ *   whole gradient arena on the main stream after backward (no cross-stream edges, one collective latency per step).  Same arithmetic, same results; which is faster depends on the
  *   all-reduce latency against the cost of a fork/join between two hardware queues (measured: DESIGN.md §7), so the host
  *   times both on the live communicator and keeps the faster (HipEngine.dp_calibrate).  Every rank must use the same setting.
  * cae_dp_eval_steps: __test_epoch on this rank's shard of each global test batch (loss scaled by 1/global count).
