@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     __shared__ float redf[4 * NRED];
     __shared__ double redd[4 * 2 * COUT];
     __shared__ __attribute__((aligned(16))) float wscr[4 * kWsumScratch];
+    __shared__ float xch[4 * CIN * 2 * 64];      // first-row shares of the four bands of a workgroup
 
 #define LF_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x < 384) a.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -131,6 +132,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     const bool last_band = band == a.bands - 1, last_strip = strip == a.strips - 1;
     const int n0 = strip * kLastStripPx + 2 * lane;      // first of the lane's two quad columns = its first pixel column
     const bool multi = a.strips > 1;
+    // With one strip per image the four waves of a workgroup are consecutive bands: a band whose neighbour below is in the
+    // same workgroup (and the same image) gets that neighbour's first-row shares through LDS instead of recomputing its row
+    const bool has_below = !multi && work && wv < 3 && band + 1 < a.bands;
+    const int nrows = has_below ? HB : NR;
     const bool all_cols = VEC4 && 256 <= a.OW;           // uniform: every lane's four output columns are inside the map
 
     // ---- loads, in the order their consumers can use them.  The wave's memory counter retires in issue order, so whatever a
@@ -200,6 +205,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
         const long long tb = a.perm ? (long long)__builtin_amdgcn_readfirstlane(perm_val_v) : bs + b;   // bs = 0 without a cursor
 #pragma unroll
         for (int r = 0; r < NR; r++) {
+            if (r >= nrows) break;       // uniform: the band below reads that row (straight-line code: no DPP in this loop)
 #pragma unroll
             for (int co = 0; co < COUT; co++) {
                 const float* plane = a.target + ((size_t)tb * COUT + co) * (size_t)OHW;
@@ -292,11 +298,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
         carry[ci][0] = carry[ci][1] = 0.f;
     }
 
-    if (work) {
+    float xsave[CIN][2];         // j = 1 shares of this band's first row: they complete the last pixel row of the band above
+#pragma unroll
+    for (int ci = 0; ci < CIN; ci++) xsave[ci][0] = xsave[ci][1] = 0.f;
+    {
         static_for<NR>([&](auto R) {
             constexpr int r = decltype(R)::value;
             const int m = m0 + r;                       // quad row; its inputs are rows m (register row r+1) and m-1 (r)
-            if (m >= a.QH) return;
+            if (work && r < nrows && m < a.QH) {        // uniform per wave (the barrier below is outside)
             const bool own_row = r < HB || last_band;   // uniform: loss / bias / weight gradients counted here
             float actN[CIN][3];
 #pragma unroll
@@ -406,6 +415,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
                 tj0[ci][0] = P[ci][0][0][0] + P[ci][1][0][1];
                 tj1[ci][1] = P[ci][1][1][0] + from_right(P[ci][0][1][1], 0.f);
                 tj0[ci][1] = P[ci][1][0][0] + from_right(P[ci][0][0][1], 0.f);
+                if (r == 0) { xsave[ci][0] = tj1[ci][0]; xsave[ci][1] = tj1[ci][1]; }
             }
             if (emit) {
                 const bool p0 = n0 < a.W, p1 = n0 + 1 < a.W && lane < 63;
@@ -435,8 +445,43 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 #pragma unroll
                 for (int k = 0; k < 3; k++) actP[ci][k] = actN[ci][k];
             }
-            if (r == 0) LF_STAMP(3);
+            }
+            if constexpr (r == 0) {
+                LF_STAMP(3);
+                // every wave, working or not: the first row's j = 1 shares go up one band through LDS
+#pragma unroll
+                for (int ci = 0; ci < CIN; ci++) {
+                    xch[((wv * CIN + ci) * 2 + 0) * 64 + lane] = xsave[ci][0];
+                    xch[((wv * CIN + ci) * 2 + 1) * 64 + lane] = xsave[ci][1];
+                }
+                __syncthreads();
+            }
         });
+    }
+    if (has_below) {
+        // HB rows computed: the last pixel row (m0 + HB - 1) is completed by the first-row shares of the band below
+        const int y = m0 + HB - 1;
+        if (y < a.H) {
+            const bool p0 = n0 < a.W, p1 = n0 + 1 < a.W && lane < 63;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ci++) {
+                float gv0 = carry[ci][0] + xch[(((wv + 1) * CIN + ci) * 2 + 0) * 64 + lane];
+                float gv1 = carry[ci][1] + xch[(((wv + 1) * CIN + ci) * 2 + 1) * 64 + lane];
+                if constexpr (BN) {
+                    const float e0 = rin[HB][ci][0] - kc[ci].x, e1 = rin[HB][ci][1] - kc[ci].x;
+                    gv0 = fmaf(e0, kc[ci].y, kc[ci].z) > 0.f ? gv0 : 0.f;
+                    gv1 = fmaf(e1, kc[ci].y, kc[ci].z) > 0.f ? gv1 : 0.f;
+                    const float s0 = p0 ? gv0 : 0.f, s1 = p1 ? gv1 : 0.f;
+                    d1[ci] += s0 + s1;
+                    d2[ci] = fmaf(s0, e0 * kc[ci].w, fmaf(s1, e1 * kc[ci].w, d2[ci]));
+                }
+                float* gp = a.gin + (size_t)(b * CIN + ci) * HW + (unsigned)y * a.W + n0;
+                if (p0) {
+                    gp[0] = gv0;
+                    gp[p1 ? 1 : 0] = p1 ? gv1 : gv0;
+                }
+            }
+        }
     }
 
     LF_STAMP(4);
