@@ -3,7 +3,15 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from cae_tools_amd.engine import HipEngine
-from bench import build_model, synthetic, FC, LATENT
+from bench import build_model, FC, LATENT
+
+
+def synthetic(n, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.rand((n, 1, 16, 16), generator=g, dtype=torch.float32)
+    t = torch.rand((n, 1, 256, 256), generator=g, dtype=torch.float32)
+    return x.to(device), t.to(device)
+
 
 spec, enc, dec = build_model(0)
 dev = torch.device("cuda", 0)
@@ -13,7 +21,7 @@ table_at = int(os.environ.get("TABLE_AT", "0"))
 for B in (int(b) for b in (sys.argv[1:] or ["64", "256"])):
     eng = HipEngine(spec, FC, LATENT, max_batch=B, device=dev)
     eng.load_state(enc.state_dict(), dec.state_dict()); eng.set_hyper(); eng.set_dataset(0, x, t)
-    perm = eng.upload_perm(np.arange(N))
+    perm = None      # batches are contiguous rows (what ConvAEModel.train and bench.py do)
     n = (N // B) * B
     for _ in range(3): eng.enqueue_train_steps(0, perm, n, B, 0)
     eng.sync(); t0 = time.perf_counter()
