@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--table", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel code path even with one rank (rehearsal)")
     ap.add_argument("--sync-bn", action="store_true", help="data-parallel runs: BatchNorm over the global batch")
+    ap.add_argument("--dp-host-allreduce", action="store_true",
+                    help="data-parallel runs: torch.distributed all-reduce between two library calls instead of the in-library RCCL path")
     ap.add_argument("--launch-order", default=None, help="write the per-step launch sequence [label, algorithmic bytes] here")
     args = ap.parse_args()
 
@@ -237,20 +239,46 @@ def main():
                 done += n
     else:
         from cae_tools_amd.dp import DataParallel, shard_bounds
-        dp = DataParallel(eng, dist, sync_bn=args.sync_bn)      # joins the library's RCCL communicator (self-tested)
-        dp.broadcast_parameters(0)
-        dp_graph = eng.dp_graph_capture()
         (lo, hi) = shard_bounds(global_batch, world, rank)
-        # the two launch structures of the exchange, timed on the live communicator; the faster is kept (untimed region)
-        dp_times = eng.dp_calibrate(dist, 0, perm, lo, hi - lo, global_batch, args.sync_bn)
+        native = not args.dp_host_allreduce
+        try:
+            if native:
+                dp = DataParallel(eng, dist, sync_bn=args.sync_bn)      # joins the library's RCCL communicator (self-tested)
+                dp.broadcast_parameters(0)
+                dp_graph = eng.dp_graph_capture()
+                # the two launch structures of the exchange, timed on the live communicator; the faster is kept (untimed region)
+                dp_times = eng.dp_calibrate(dist, 0, perm, lo, hi - lo, global_batch, args.sync_bn)
+        except Exception as ex:      # the in-library communicator could not be set up on this rank
+            print(f"[bench rank {rank}] in-library data parallelism unavailable ({ex}); torch.distributed all-reduce instead",
+                  file=sys.stderr)
+            native = False
+        ok = torch.tensor([1 if native else 0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # every rank takes the same path
+        native = bool(ok.item())
 
-        def run(nsteps):
-            done = 0
-            while done < nsteps:
-                n = min(steps_per_epoch, nsteps - done)      # one epoch's steps: ONE call = one graph replay
-                eng.set_cursor(lo, 0)
-                eng.dp_train_steps(0, perm, hi - lo, global_batch, args.sync_bn, n)
-                done += n
+        if native:
+            def run(nsteps):
+                done = 0
+                while done < nsteps:
+                    n = min(steps_per_epoch, nsteps - done)      # one epoch's steps: ONE call = one graph replay
+                    eng.set_cursor(lo, 0)
+                    eng.dp_train_steps(0, perm, hi - lo, global_batch, args.sync_bn, n)
+                    done += n
+        else:
+            # fallback (round 1's protocol, also --dp-host-allreduce): per step cae_forward_backward, the gradient arena
+            # all-reduced by torch.distributed (RCCL) on the engine's stream, cae_adam_step; per-rank BatchNorm statistics
+            class _HalfSteps:        # hides the in-library entry points from DataParallel
+                def __init__(self, e):
+                    (self.e, self.grads, self.params, self.buffers, self.exp_avg, self.exp_avg_sq) = \
+                        (e, e.grads, e.params, e.buffers, e.exp_avg, e.exp_avg_sq)
+                    (self.stream, self.device, self.forward_backward, self.adam_step) = (e.stream, e.device, e.forward_backward, e.adam_step)
+            dp = DataParallel(_HalfSteps(eng), dist, sync_bn=False)
+            dp.broadcast_parameters(0)
+            (dp_graph, dp_times) = (False, {})
+
+            def run(nsteps):
+                for k in range(nsteps):
+                    dp.train_step(0, perm, (k % steps_per_epoch) * global_batch + lo, hi - lo, global_batch)
 
     def barrier():
         if dist is not None:
@@ -286,7 +314,9 @@ def main():
                        "global_batch": BATCH * world, "n_train": N_TRAIN, "params": 112271,
                        "parallelism": (f"dp{world}" + ("+syncbn" if args.sync_bn else "")) if dist is not None else "single",
                        "dp_collectives": None if dist is None else
-                       (("RCCL all-reduce of 2 gradient buckets, first one on a second stream beside the tail of backward"
+                       ("torch.distributed all-reduce of the gradient arena between cae_forward_backward and cae_adam_step, plain launches"
+                        if not native else
+                        ("RCCL all-reduce of 2 gradient buckets, first one on a second stream beside the tail of backward"
                          if eng.dp_overlap and not args.sync_bn else
                          "one RCCL all-reduce of the whole gradient arena on the main stream after backward" if not args.sync_bn else
                          "RCCL all-reduce of 2 gradient buckets and of every BatchNorm sum table on the main stream") +
