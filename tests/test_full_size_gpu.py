@@ -70,3 +70,53 @@ def test_scoring_and_properties_at_benchmark_size():
     s2 = eng.forward_backward(0, eng.upload_perm(perm), 0, 64, 64); l2 = eng._read_losses(s2, 1)[0]; eng.sync(); g2 = eng.grads.clone()
     assert abs(l1 - l2) <= 1e-9 * abs(l1)   # per-block fp32 partials regroup; fp64 across blocks
     assert float((g1 - g2).abs().max()) <= 1e-6 * float(g1.abs().max())
+
+
+@pytest.mark.parametrize("in_size,out_size,batch", [((32, 32), (512, 512), 3), ((20, 36), (300, 540), 2), ((8, 8), (128, 128), 5)])
+def test_other_geometries_of_the_row_and_fused_kernels(in_size, out_size, batch):
+    """Geometries that take the other branches of round 2's kernels (kernels_last.h, kernels_rows.h) than the benchmark does:
+    32x32 -> 512x512: the last layer's input is 255 wide = three strips of the fused last-layer kernel (scalar target loads,
+    strip-edge ownership, lane 0's left-hand column), the middle layers are wider than a wave (round 1's tile kernels);
+    20x36 -> 300x540: non-square, odd widths, rows that end inside a lane's column pair;
+    8x8 -> 128x128: maps of 16 and 32 quad columns (two images per wave, partly empty waves), an odd batch.
+    One training step (loss, every gradient) and one scoring pass against the CPU oracle."""
+    from cae_tools_amd.engine import HipEngine
+    from cae_tools_amd.models.model_sizer import create_model_spec
+    from cae_tools_amd.models.encoder import Encoder
+    from cae_tools_amd.models.decoder import Decoder
+    from oracle import cae_oracle as orc
+    from helpers import bn_bias_keys
+    torch.set_num_threads(8)
+    spec = create_model_spec(input_size=in_size, input_channels=1, output_size=out_size, output_channels=1)
+    torch.manual_seed(17)
+    enc = Encoder(spec.get_input_layers(), encoded_space_dim=8, fc_size=32)
+    dec = Decoder(spec.get_output_layers(), encoded_space_dim=8, fc_size=32)
+    g = torch.Generator().manual_seed(18)
+    x = torch.rand((batch, 1) + in_size, generator=g)
+    t = torch.rand((batch, 1) + out_size, generator=g)
+    eng = HipEngine(spec, 32, 8, max_batch=8)
+    eng.load_state(enc.state_dict(), dec.state_dict())
+    eng.set_hyper(lr=1e-3, weight_decay=1e-5)
+    eng.set_dataset(0, x.cuda(), t.cuda())
+    ref = orc.OracleModel(spec.save(), enc.state_dict(), dec.state_dict(), lr=1e-3, weight_decay=1e-5)
+    slot = eng.forward_backward(0, None, 0, batch, batch)
+    loss = eng._read_losses(slot, 1)[0]
+    eng.sync()
+    loss_ref, _ = ref.loss_and_grads(x, t)
+    assert abs(loss - loss_ref) <= 2e-6 * abs(loss_ref)
+    noisy = bn_bias_keys(spec.save())
+    for k, gr in ref.grads().items():
+        if k in noisy:
+            continue
+        got = eng.grad_view(k).cpu().numpy()
+        scale = float(gr.abs().max())
+        # small batches make BatchNorm ill-conditioned (DESIGN.md §2): fp32 against fp32
+        assert float(np.abs(got - gr.numpy()).max()) <= 2e-3 * scale + 1e-9, k
+    y = eng.score(x.cuda()).cpu()
+    assert float((y - ref.eval_forward(x)).abs().max()) <= 2e-5
+    # and the step did take the kernels this test is about (not a fallback): the launch labels of a profiled step
+    eng.profile_begin()
+    eng.forward_backward(0, None, 0, batch, batch)
+    labels = {name for (name, layer, us, nbytes) in eng.profile_end()}
+    assert "s2_convt_last_fused" in labels, labels
+    assert "s2_convt_bwd" in labels and "s2_convt_fwd" in labels, labels
