@@ -643,7 +643,8 @@ bool head_plan(const cae_engine* e, const StepArgs& a, HeadArgs& h, size_t& lds_
     h.momentum = kBnMomentum;
     h.eps = kBnEps;
     h.st = e->state();
-    h.tiles_per_wg = 4;
+    static const int tpw = env_int("CAE_HEAD_TPW", 4);   // env: tuning only - Linear-3 column tiles per workgroup
+    h.tiles_per_wg = tpw < 1 ? 1 : tpw;
     double* acc = e->gradacc();
     int64_t top = 0;
     auto take = [&](int64_t floats) {
