@@ -2070,6 +2070,8 @@ int cae_dp_init(cae_engine* e, int world, int rank, const void* id128_host) {
     // warm the size classes a step uses: the two gradient buckets (self-test) and the BatchNorm tables (fp64, on the
     // main stream), on the gradient arena as scratch - its contents mean nothing between steps
     if (int rc = dp_self_test(e)) return rc;
+    // the whole arena in one collective (the structure without overlap): its size class too is met outside any capture first
+    if (int rc = dp_allreduce_grads(e, 0, e->n_param, e->stream)) return rc;
     for (int c : e->bn_channels) {
         const size_t nd = (size_t)kStatShards * c * 4;
         if ((int64_t)nd * 2 > e->n_param) continue;
