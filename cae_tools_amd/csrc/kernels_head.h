@@ -202,9 +202,23 @@ __device__ __forceinline__ double head_wave_sum(double v) { return wave_sum_lane
 // Everything small the kernel reads from global memory (encoder parameters and running statistics, Linear biases), copied
 // to LDS in ONE burst of loads: one element per thread per segment, all loads issued before the first store.  The sample
 // gather (cursor -> permutation -> input rows: three dependent hops) is started first and lands in LDS last.
-__device__ __forceinline__ void head_stage_inputs(const HeadArgs& a, float* lds) {
+// `bs`: the cursor (StepState.batch_start), requested by the caller at the top of the kernel so that its round trip hides
+// behind the weight loads' issue.  Without a permutation (batches laid out contiguously once: ConvAEModel.train, bench.py) the
+// batch is ONE contiguous block starting at row bs: its loads are issued first and need no sample table.
+__device__ __forceinline__ void head_stage_inputs(const HeadArgs& a, float* lds, long long bs) {
     const int tid = threadIdx.x;
     int* sample = reinterpret_cast<int*>(lds + a.o_perm);
+    const HeadConv& L0 = a.enc[0];
+    const int per = L0.cin * L0.hin * L0.win;
+    float* xs = lds + a.o_x;
+    const bool direct = a.perm == nullptr && (per & 3) == 0 && a.B * (per >> 2) <= 4 * kHeadThreads;
+    f32x4 xv[4];
+    if (direct) {
+        const int total = a.B * (per >> 2);
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.x + (size_t)bs * per);
+#pragma unroll
+        for (int u = 0; u < 4; u++) xv[u] = src[min(tid + u * kHeadThreads, total - 1)];
+    }
     float v[kHeadMaxSeg];
 #pragma unroll
     for (int g = 0; g < kHeadMaxSeg; g++) {
@@ -214,17 +228,25 @@ __device__ __forceinline__ void head_stage_inputs(const HeadArgs& a, float* lds)
             v[g] = src[min(tid, a.seg[g].count - 1)];
         }
     }
-    int smp = 0;
-    if (tid < a.B) smp = (int)sample_of(a.perm, a.use_cursor, a.st, tid);
-    for (int b = tid + kHeadThreads; b < a.B; b += kHeadThreads) sample[b] = (int)sample_of(a.perm, a.use_cursor, a.st, b);
-    if (tid < a.B) sample[tid] = smp;
+    if (!direct) {
+        int smp = 0;
+        if (tid < a.B) smp = a.perm ? a.perm[bs + tid] : (int)(bs + tid);
+        for (int b = tid + kHeadThreads; b < a.B; b += kHeadThreads) sample[b] = a.perm ? a.perm[bs + b] : (int)(bs + b);
+        if (tid < a.B) sample[tid] = smp;
+    }
 #pragma unroll
     for (int g = 0; g < kHeadMaxSeg; g++)
         if (g < a.n_seg && tid < a.seg[g].count) lds[a.seg[g].lds_off + tid] = v[g];
+    if (direct) {
+        const int total = a.B * (per >> 2);
+        f32x4* xs4 = reinterpret_cast<f32x4*>(xs);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (tid + u * kHeadThreads < total) xs4[tid + u * kHeadThreads] = xv[u];
+        __syncthreads();
+        return;
+    }
     __syncthreads();
-    const HeadConv& L0 = a.enc[0];
-    const int per = L0.cin * L0.hin * L0.win;
-    float* xs = lds + a.o_x;
     if ((per & 3) == 0) {
         const int n4 = per >> 2, total = a.B * n4;
         const float inv_n4 = 1.0f / (float)n4;
@@ -385,6 +407,8 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(HeadArgs a) {
     if (first && tid == 0 && a.bump_adam) const_cast<StepState*>(a.st)->adam_step += 1;
 
     head_stamp(a, 0);
+    // the cursor first: the input batch hangs off it (head_stage_inputs)
+    const long long bs = (a.perm || a.use_cursor) ? a.st->batch_start : 0;
     const int T3 = (a.fc[3].nout + 15) >> 4;
     const int tn3 = blockIdx.y * a.tiles_per_wg;
     const int TN3 = min(a.tiles_per_wg, T3 - tn3);
@@ -400,7 +424,7 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(HeadArgs a) {
     }
     for (int i = tid; i < 32 * a.ld_h + 32; i += kHeadThreads) lds[a.o_h[0] + i] = 0.f;   // both panels (adjacent), padding and guard included
     head_stamp(a, 1);
-    head_stage_inputs(a, lds);
+    head_stage_inputs(a, lds, bs);
     head_stamp(a, 2);
     head_encoder(a, lds, first);
     head_stamp(a, 3);
