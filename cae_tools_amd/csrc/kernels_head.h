@@ -39,6 +39,7 @@ struct StageSplit {
     int lg, per;
 };
 
+constexpr int kHeadEarly = 5;   // of which requested at kernel start (k_head_fwd)
 constexpr int kHeadW4 = 8;      // float4s of Linear weights a thread carries from kernel start to the LDS copy
 struct HeadW {
     const float* src;   // row-major [rows][4 * n4row]
@@ -213,7 +214,7 @@ __device__ __forceinline__ void head_stage_inputs(const HeadArgs& a, float* lds,
     float* xs = lds + a.o_x;
     const bool direct = a.perm == nullptr && (per & 3) == 0 && a.B * (per >> 2) <= 4 * kHeadThreads;
     f32x4 xv[4];
-    if (direct) {
+    if (direct) {   // the first use of the cursor: a counted wait (it was the first load), the Linear weights stay in flight
         const int total = a.B * (per >> 2);
         const f32x4* src = reinterpret_cast<const f32x4*>(a.x + (size_t)bs * per);
 #pragma unroll
@@ -295,7 +296,12 @@ __device__ __forceinline__ void head_encoder(const HeadArgs& a, float* lds, bool
         const bool k3 = L.kh == 3 && L.kw == 3;
         const float4* kin = l ? reinterpret_cast<const float4*>(lds + a.enc[l - 1].o_c) : nullptr;
         // four output channels at a time share the position arithmetic and the (BatchNorm + ReLU'd) input taps; the
-        // weights are wave-uniform reads of the parameter arena (scalar loads)
+        // weights and biases are broadcast reads of their LDS copy (head_stage_inputs).  Read from the parameter arena they
+        // are vector loads - the compiler cannot prove the arena unchanged across this kernel's stores, so no scalar loads -
+        // each waited for with vmcnt(0) inside the channel loop: a trip to L2 per iteration, and the first one drains the
+        // Linear weights still in flight.  (The phase itself is bound by instruction issue - one workgroup computes the whole
+        // batch on one CU - and did not get shorter: 8.0 -> 8.7 us with the weight loads no longer waited for ahead of it.)
+        const float* bl = lds + L.o_b;
         for (int c0 = 0; c0 < L.cout; c0 += 4) {
             int cj[4];
 #pragma unroll
@@ -307,7 +313,7 @@ __device__ __forceinline__ void head_encoder(const HeadArgs& a, float* lds, bool
                 const int o_in = (y * L.s) * L.win + x * L.s;
                 float acc[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[j] = L.bias[cj[j]];
+                for (int j = 0; j < 4; j++) acc[j] = bl[cj[j]];
                 for (int cl = 0; cl < L.cin; cl++) {
                     const float* ip = yin + (b * L.cin + cl) * ihw + o_in;
                     const float4 kb = l ? kin[cl] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -323,7 +329,7 @@ __device__ __forceinline__ void head_encoder(const HeadArgs& a, float* lds, bool
                         }
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            const float* __restrict__ wp = L.w + (cj[j] * L.cin + cl) * 9;
+                            const float* wp = wl + (cj[j] * L.cin + cl) * 9;
 #pragma unroll
                             for (int i = 0; i < 9; i++) acc[j] = fmaf(v[i], wp[i], acc[j]);
                         }
@@ -333,7 +339,7 @@ __device__ __forceinline__ void head_encoder(const HeadArgs& a, float* lds, bool
                                 float v = ip[ky * L.win + kx];
                                 if (l) v = fmaxf(0.f, fmaf(v - kb.x, kb.y, kb.z));
 #pragma unroll
-                                for (int j = 0; j < 4; j++) acc[j] = fmaf(v, L.w[(cj[j] * L.cin + cl) * taps + ky * L.kw + kx], acc[j]);
+                                for (int j = 0; j < 4; j++) acc[j] = fmaf(v, wl[(cj[j] * L.cin + cl) * taps + ky * L.kw + kx], acc[j]);
                             }
                     }
                 }
@@ -407,26 +413,64 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(HeadArgs a) {
     if (first && tid == 0 && a.bump_adam) const_cast<StepState*>(a.st)->adam_step += 1;
 
     head_stamp(a, 0);
-    // the cursor first: the input batch hangs off it (head_stage_inputs)
-    const long long bs = (a.perm || a.use_cursor) ? a.st->batch_start : 0;
+    // The cursor first: the input batch hangs off it (head_stage_inputs).  Read through an index the compiler cannot see is
+    // zero: a load it knows to be wave-uniform is moved to a scalar register at once, i.e. waited for here, with nothing
+    // else in flight yet.
+    long long bs = 0;
+    if (a.perm || a.use_cursor) {
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        bs = (&a.st->batch_start)[z];
+    }
     const int T3 = (a.fc[3].nout + 15) >> 4;
     const int tn3 = blockIdx.y * a.tiles_per_wg;
     const int TN3 = min(a.tiles_per_wg, T3 - tn3);
     // The Linear weights, as coalesced 16-byte loads that stay in flight while the encoder runs (fetching them in the MFMA
     // operand layout instead costs 16 cache lines per wave instruction: measured 10 us for the four layers).
-    f32x4 wreg[kHeadW4];
+    // (the matrix a 16-byte piece belongs to is picked with selects between wave-uniform values: indexing a.wmat[] with a
+    // per-lane index makes the compiler fetch the descriptor fields from the kernel argument segment with per-lane loads,
+    // a dependent trip to memory ahead of every weight load)
+    // Only the first kHeadEarly pieces per thread are carried across the encoder: with all of them the register allocator
+    // (128 VGPRs at 1024 threads) spills two right where they are loaded, which waits for every load at the top of the
+    // kernel.  The rest - the tail of the piece order, i.e. the last Linear layer's - is requested after the encoder and
+    // lands behind the first Linear layer.
+    const int st1 = a.wmat[1].start4, st2 = a.wmat[2].start4, st3 = a.wmat[3].start4;
+    auto load_piece = [&](int j) {
+        const f32x4* wsrc[4];
 #pragma unroll
-    for (int j = 0; j < kHeadW4; j++) {
+        for (int m = 0; m < 4; m++)
+            wsrc[m] = reinterpret_cast<const f32x4*>(a.wmat[m].src + (size_t)blockIdx.y * a.wmat[m].strip_floats) - a.wmat[m].start4;
         const int idx = min(tid + j * kHeadThreads, a.w_total4 - 1);
-        const int m = (idx >= a.wmat[1].start4) + (idx >= a.wmat[2].start4) + (idx >= a.wmat[3].start4);
-        const float* src = a.wmat[m].src + (size_t)blockIdx.y * a.wmat[m].strip_floats;
-        wreg[j] = reinterpret_cast<const f32x4*>(src)[idx - a.wmat[m].start4];
-    }
+        const f32x4* src = idx >= st3 ? wsrc[3] : idx >= st2 ? wsrc[2] : idx >= st1 ? wsrc[1] : wsrc[0];
+        return src[idx];
+    };
+    auto store_piece = [&](int j, const f32x4& val) {
+        const int idx = tid + j * kHeadThreads;
+        if (idx < a.w_total4) {
+            const bool m3 = idx >= st3, m2 = idx >= st2, m1 = idx >= st1;
+            auto pick = [&](int v0, int v1, int v2, int v3) { return m3 ? v3 : m2 ? v2 : m1 ? v1 : v0; };
+            const int local = idx - pick(0, st1, st2, st3);
+            const int n4row = pick(a.wmat[0].n4row, a.wmat[1].n4row, a.wmat[2].n4row, a.wmat[3].n4row);
+            const int ldw = pick(a.wmat[0].ldw, a.wmat[1].ldw, a.wmat[2].ldw, a.wmat[3].ldw);
+            const int off = pick(a.wmat[0].lds_off, a.wmat[1].lds_off, a.wmat[2].lds_off, a.wmat[3].lds_off);
+            const int row = div_small(local, 1.0f / (float)n4row);
+            *reinterpret_cast<f32x4*>(lds + off + row * ldw + 4 * (local - row * n4row)) = val;
+        }
+    };
+    f32x4 wreg[kHeadEarly];
+#pragma unroll
+    for (int j = 0; j < kHeadEarly; j++) wreg[j] = load_piece(j);
     for (int i = tid; i < 32 * a.ld_h + 32; i += kHeadThreads) lds[a.o_h[0] + i] = 0.f;   // both panels (adjacent), padding and guard included
     head_stamp(a, 1);
     head_stage_inputs(a, lds, bs);
     head_stamp(a, 2);
     head_encoder(a, lds, first);
+    f32x4 wlate[kHeadW4 - kHeadEarly];
+    const bool late = a.w_total4 > kHeadEarly * kHeadThreads;   // uniform
+    if (late) {
+#pragma unroll
+        for (int j = kHeadEarly; j < kHeadW4; j++) wlate[j - kHeadEarly] = load_piece(j);
+    }
     head_stamp(a, 3);
 
     const int row0 = blockIdx.x * 16;
@@ -449,15 +493,7 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(HeadArgs a) {
     }
     // the encoder's input and inner maps are dead: the weights take their place
 #pragma unroll
-    for (int j = 0; j < kHeadW4; j++) {
-        const int idx = tid + j * kHeadThreads;
-        if (idx < a.w_total4) {
-            const int m = (idx >= a.wmat[1].start4) + (idx >= a.wmat[2].start4) + (idx >= a.wmat[3].start4);
-            const int local = idx - a.wmat[m].start4;
-            const int row = div_small(local, 1.0f / (float)a.wmat[m].n4row);
-            *reinterpret_cast<f32x4*>(lds + a.wmat[m].lds_off + row * a.wmat[m].ldw + 4 * (local - row * a.wmat[m].n4row)) = wreg[j];
-        }
-    }
+    for (int j = 0; j < kHeadEarly; j++) store_piece(j, wreg[j]);
     __syncthreads();
     head_stamp(a, 4);
     const bool store_h = blockIdx.y == 0 && a.train;
@@ -488,6 +524,10 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(HeadArgs a) {
         head_stamp(a, 5 + i);
     };
     run_fc(std::integral_constant<int, 0>{});
+    if (late) {   // their LDS rows are not read before the barriers of the next stage
+#pragma unroll
+        for (int j = kHeadEarly; j < kHeadW4; j++) store_piece(j, wlate[j - kHeadEarly]);
+    }
     run_fc(std::integral_constant<int, 1>{});
     run_fc(std::integral_constant<int, 2>{});
     run_fc(std::integral_constant<int, 3>{});
