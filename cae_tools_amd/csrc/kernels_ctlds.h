@@ -75,7 +75,9 @@ __global__ void __launch_bounds__(512) k_ct_fwd_lds(CtFwd a) {
     float* wl = reinterpret_cast<float*>(cin4 + a.Cin);             // [Cin][16][KKp]
     float* img = wl + a.Cin * WS;                                   // [Cin][plane]
     float* part = img + ((a.Cin * a.plane + 3) & ~3);               // [waves][16 regs][64 lanes]
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    // (not blockDim.x: the compiler fetches that from the hidden kernel arguments with a per-lane load, and every address
+    // below waits for it)
+    const int tid = threadIdx.x, nthr = 64 * a.rt * a.ks;
     const int b = blockIdx.x / a.tg, g = blockIdx.x - b * a.tg, cb = blockIdx.y;
 
     // Every global read of the prologue is issued before anything waits: the image (in source order: coalesced, no
@@ -96,18 +98,21 @@ __global__ void __launch_bounds__(512) k_ct_fwd_lds(CtFwd a) {
         const int n4 = ncol * KK / 4, total4 = a.Cin * n4;
         const float inv_n4 = 1.0f / (float)n4;
         for (int i0 = tid; i0 < total4; i0 += 6 * nthr) {
-            float4 wv4[6];
+            f32x4 wv4[6];
             int dst[6];
 #pragma unroll
             for (int u = 0; u < 6; u++) {
                 const int idx = min(i0 + u * nthr, total4 - 1);
                 const int ci = div_small(idx, inv_n4), jq = idx - ci * n4;
-                wv4[u] = *reinterpret_cast<const float4*>(wsrc + (size_t)ci * wstride + 4 * jq);
+                wv4[u] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)ci * wstride + 4 * jq);
                 dst[u] = ci * WS + 4 * jq;
             }
+            // keeps the compiler from sinking each load into its conditional store below (load, wait, store, six times over:
+            // six trips to memory one after the other)
+            asm volatile("" : "+v"(wv4[0]), "+v"(wv4[1]), "+v"(wv4[2]), "+v"(wv4[3]), "+v"(wv4[4]), "+v"(wv4[5]));
 #pragma unroll
             for (int u = 0; u < 6; u++)
-                if (i0 + u * nthr < total4) *reinterpret_cast<float4*>(wl + dst[u]) = wv4[u];
+                if (i0 + u * nthr < total4) *reinterpret_cast<f32x4*>(wl + dst[u]) = wv4[u];
         }
         if (ncol < 16) {   // columns past Cout: zero B operands
             const int tail = WS - ncol * KK;
@@ -116,7 +121,12 @@ __global__ void __launch_bounds__(512) k_ct_fwd_lds(CtFwd a) {
                 wl[ci * WS + ncol * KK + (idx - ci * tail)] = 0.f;
             }
         }
-    } else {
+    }
+    bn_consts(a.bn_in, cin4, blockIdx.x == 0 && blockIdx.y == 0);
+    // (the general weight path comes after everything the common one issues: placed ahead of it, its loads - never
+    // executed then - still count as pending where the paths meet, and the common path waits for the image before it
+    // requests the weights)
+    if (!vec) {
         for (int i0 = tid; i0 < a.Cin * WS; i0 += 8 * nthr) {
             float wv1[8];
             bool ok[8];
@@ -133,7 +143,6 @@ __global__ void __launch_bounds__(512) k_ct_fwd_lds(CtFwd a) {
                 if (i0 + u * nthr < a.Cin * WS) wl[i0 + u * nthr] = ok[u] ? wv1[u] : 0.f;
         }
     }
-    bn_consts(a.bn_in, cin4, blockIdx.x == 0 && blockIdx.y == 0);
     if (tid < 32) lstat[tid] = 0.0;
     {   // zero the padded image (its border stays zero: a tap outside the map then needs no predicate)
         const int n4 = (a.Cin * a.plane + 3) >> 2;

@@ -180,47 +180,70 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 //   BN_BWD:           {mean, k1, k2, k3}  with  gy = k1*g - k2 - (y-mean)*k3
 __device__ __forceinline__ void bn_consts(const BnDesc& d, float4* out, bool designated) {
     if (d.mode == BN_NONE) return;
+    // Every consumer's prologue runs this on its critical path, so within a mode every global read is requested before the
+    // first wait and before the first store (a store to memory the reads might alias pins the later reads behind it: the
+    // sums, then gamma and beta, then the running statistics used to be three to four trips to memory, one after the other).
     for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
         float mean, invstd;
+        const float gamma = d.gamma[c];
         if (d.mode == BN_BATCH) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int sh = 0; sh < kStatShards; sh++) {
-                s1 += d.stats[((size_t)sh * d.C + c) * 4];
-                s2 += d.stats[((size_t)sh * d.C + c) * 4 + 1];
+            double2 t[kStatShards];
+#pragma unroll
+            for (int sh = 0; sh < kStatShards; sh++) t[sh] = *reinterpret_cast<const double2*>(d.stats + ((size_t)sh * d.C + c) * 4);
+            const float beta = d.beta[c];
+            const bool upd = designated && d.update;
+            float rm = 0.f, rv = 0.f;
+            if (upd) {
+                rm = d.rmean[c];
+                rv = d.rvar[c];
             }
-            // every consumer's prologue runs this on its critical path: multiplications by host-computed reciprocals and
-            // an fp32 square root instead of three fp64 divisions and an fp64 square root
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int sh = 0; sh < kStatShards; sh++) {
+                s1 += t[sh].x;
+                s2 += t[sh].y;
+            }
+            // multiplications by host-computed reciprocals and an fp32 square root instead of three fp64 divisions and an
+            // fp64 square root
             const double m = s1 * d.inv_count;
             double var = s2 * d.inv_count - m * m;
             var = var < 0.0 ? 0.0 : var;
             mean = (float)m;
             invstd = 1.0f / sqrtf((float)(var + (double)d.eps));
-            if (designated && d.update) {
+            out[c] = make_float4(mean, gamma * invstd, beta, invstd);
+            if (upd) {
                 d.saved[2 * c] = mean;
                 d.saved[2 * c + 1] = invstd;
                 const double unb = var * d.unbias;
-                d.rmean[c] = (1.f - d.momentum) * d.rmean[c] + d.momentum * mean;
-                d.rvar[c] = (1.f - d.momentum) * d.rvar[c] + d.momentum * (float)unb;
+                d.rmean[c] = (1.f - d.momentum) * rm + d.momentum * mean;
+                d.rvar[c] = (1.f - d.momentum) * rv + d.momentum * (float)unb;
             }
         } else if (d.mode == BN_RUNNING) {
+            const float beta = d.beta[c];
             mean = d.rmean[c];
             invstd = 1.0f / sqrtf(d.rvar[c] + d.eps);
-        } else {
+            out[c] = make_float4(mean, gamma * invstd, beta, invstd);
+        } else if (d.mode == BN_BWD) {
+            double2 t[kStatShards];
+#pragma unroll
+            for (int sh = 0; sh < kStatShards; sh++) t[sh] = *reinterpret_cast<const double2*>(d.stats + ((size_t)sh * d.C + c) * 4 + 2);
             mean = d.saved[2 * c];
             invstd = d.saved[2 * c + 1];
-        }
-        const float scale = d.gamma[c] * invstd;
-        if (d.mode == BN_BWD) {
             double dbeta = 0.0, dgamma = 0.0;
+#pragma unroll
             for (int sh = 0; sh < kStatShards; sh++) {
-                dbeta += d.stats[((size_t)sh * d.C + c) * 4 + 2];
-                dgamma += d.stats[((size_t)sh * d.C + c) * 4 + 3];
+                dbeta += t[sh].x;
+                dgamma += t[sh].y;
             }
+            const float scale = gamma * invstd;
             const float k2 = (float)((double)scale * dbeta * d.inv_count);
             const float k3 = (float)((double)scale * (double)invstd * dgamma * d.inv_count);
             out[c] = make_float4(mean, scale, k2, k3);
-        } else {
-            out[c] = make_float4(mean, scale, d.beta[c], invstd);
+        } else {   // saved statistics of this step (activation recomputed in the backward pass)
+            const float beta = d.beta[c];
+            mean = d.saved[2 * c];
+            invstd = d.saved[2 * c + 1];
+            out[c] = make_float4(mean, gamma * invstd, beta, invstd);
         }
     }
 }

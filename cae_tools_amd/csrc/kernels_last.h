@@ -141,9 +141,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     // ---- loads, in the order their consumers can use them.  The wave's memory counter retires in issue order, so whatever a
     // value's consumer waits for, it waits for everything issued before it: the small dependent reads (cursor -> permutation
     // -> target row; BatchNorm sums; weights) go first and the band's bulk behind them, never the other way round.
-    long long bs = 0;
+    // (zero offsets hidden from the compiler in a vector register: a load it knows to be wave-uniform is moved to a scalar
+    // register - and waited for - where it is issued; the cursor would cost a trip to memory with nothing else in flight)
+    int lane_zero = 0;
+    asm volatile("" : "+v"(lane_zero));
+    long long bs_v = 0;
     const bool indirect = a.perm != nullptr || a.use_cursor != 0;
-    if (indirect) bs = a.st->batch_start;
+    if (indirect) bs_v = (&a.st->batch_start)[lane_zero];
     // BatchNorm sums of the producer: lane (8 c + shard) reads that shard's {sum y, sum y^2} of channel c (one 16-byte load)
     double sa = 0.0, sb = 0.0;
     float gam[CIN], bet[CIN], rmn[CIN], rvr[CIN];
@@ -173,12 +177,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     __builtin_amdgcn_sched_barrier(0);
     // the permutation entry is requested here and waited for behind the input loads (branch-free: without a permutation the
     // load reads a dummy word of the step state)
-    // (the zero offset is hidden from the compiler in a vector register: a load it knows to be uniform is moved to a scalar
-    // register - and waited for - where it is issued)
-    int lane_zero = 0;
-    asm volatile("" : "+v"(lane_zero));
-    const int* perm_src = (a.perm ? a.perm + (bs + b) : reinterpret_cast<const int*>(a.st)) + lane_zero;
-    const int perm_val_v = *perm_src;
+    // (uniform branch: only this path waits for the cursor here.  Left unset otherwise, on purpose: writing the register in
+    // the other path makes the compiler drain every load in flight first, since a load may be pending on it)
+    int perm_val_v;
+    if (a.perm) perm_val_v = a.perm[bs_v + b + lane_zero];
     // Inputs: rows m0-1 .. m0+HB, columns n0, n0+1 (+ column n0-1 for lane 0 of a later strip); clamped addresses, validity
     // by select.  Targets: output rows 2m, 2m+1 of every quad row, four columns from 2 n0.
     constexpr int NLEFT = VEC4 ? 1 : NR + 1;   // one strip: nothing to the left of lane 0
@@ -202,6 +204,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        // (the cursor was the first load: a counted wait, the inputs stay in flight)
+        const long long bs = ((long long)__builtin_amdgcn_readfirstlane((int)(bs_v >> 32)) << 32) |
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)bs_v);
         const long long tb = a.perm ? (long long)__builtin_amdgcn_readfirstlane(perm_val_v) : bs + b;   // bs = 0 without a cursor
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -527,6 +532,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
         }
     }
     LF_STAMP(5);
+    // keeps the permutation value's register its own to the end: were it reused, every write to it would wait for the
+    // load that may be pending on it (and, the counter being in order, for the BatchNorm sums and weights ahead of it)
+    asm volatile("" :: "v"(perm_val_v));
 #undef LF_STAMP
 }
 
