@@ -89,6 +89,14 @@ __global__ void __launch_bounds__(512) k_ct_fwd_lds(CtFwd a) {
 #pragma unroll
     for (int u = 0; u < kCtImgRegs; u++) iv[u] = src[min(tid + u * nthr, n_img - 1)];
 
+    // the producer's BatchNorm sums (the usual mode: batch statistics, one thread per input channel) are requested here, with
+    // the image and ahead of the weights, and turned into constants behind the weight stores: one wait covers all three
+    const bool bn_designated = blockIdx.x == 0 && blockIdx.y == 0;
+    const bool bn_split = a.bn_in.mode == BN_BATCH && a.bn_in.C <= nthr;   // uniform
+    const bool bn_mine = bn_split && tid < a.bn_in.C, bn_upd = bn_designated && a.bn_in.update;
+    BnBatchReq bnrq;
+    if (bn_mine) bn_batch_request(a.bn_in, tid, bn_upd, bnrq);
+
     const int ncol = min(16, a.Cout - cb * 16);
     const float* wsrc = a.w + (size_t)cb * 16 * KK;
     const int wstride = a.Cout * KK;
@@ -122,7 +130,11 @@ __global__ void __launch_bounds__(512) k_ct_fwd_lds(CtFwd a) {
             }
         }
     }
-    bn_consts(a.bn_in, cin4, blockIdx.x == 0 && blockIdx.y == 0);
+    if (bn_split) {
+        if (bn_mine) bn_batch_finish(a.bn_in, tid, bn_upd, bnrq, cin4);
+    } else {
+        bn_consts(a.bn_in, cin4, bn_designated);
+    }
     // (the general weight path comes after everything the common one issues: placed ahead of it, its loads - never
     // executed then - still count as pending where the paths meet, and the common path waits for the image before it
     // requests the weights)

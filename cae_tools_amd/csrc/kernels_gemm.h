@@ -51,7 +51,7 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g, const int bx, dou
     float4* ca = reinterpret_cast<float4*>(lstat + 128);
     float4* cc = ca + (g.bn_a.mode ? g.bn_a.C : 0);
     bn_consts(g.bn_a, ca, bx == 0);
-    bn_consts(g.bn_c, cc, false);
+    bn_consts(g.bn_c, cc, false, 64);
     if (threadIdx.x < 128) lstat[threadIdx.x] = 0.f;
     __syncthreads();
 

@@ -178,47 +178,70 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 // Per-channel constants for a BnDesc into LDS.
 //   activation modes: {mean, gamma*invstd, beta, invstd}
 //   BN_BWD:           {mean, k1, k2, k3}  with  gy = k1*g - k2 - (y-mean)*k3
-__device__ __forceinline__ void bn_consts(const BnDesc& d, float4* out, bool designated) {
+// BN_BATCH constants of channel c in two halves, so that a prologue can request the sums before its other loads and
+// finish behind them: request = every global read, finish = arithmetic, the LDS entry and (upd) the running statistics.
+struct BnBatchReq {
+    double2 t[kStatShards];
+    float gamma, beta, rm, rv;
+};
+__device__ __forceinline__ void bn_batch_request(const BnDesc& d, int c, bool upd, BnBatchReq& r) {
+    r.gamma = d.gamma[c];
+#pragma unroll
+    for (int sh = 0; sh < kStatShards; sh++) r.t[sh] = *reinterpret_cast<const double2*>(d.stats + ((size_t)sh * d.C + c) * 4);
+    r.beta = d.beta[c];
+    r.rm = 0.f;
+    r.rv = 0.f;
+    if (upd) {
+        r.rm = d.rmean[c];
+        r.rv = d.rvar[c];
+    }
+}
+__device__ __forceinline__ void bn_batch_finish(const BnDesc& d, int c, bool upd, const BnBatchReq& r, float4* out) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int sh = 0; sh < kStatShards; sh++) {
+        s1 += r.t[sh].x;
+        s2 += r.t[sh].y;
+    }
+    // multiplications by host-computed reciprocals and an fp32 square root instead of three fp64 divisions and an fp64
+    // square root
+    const double m = s1 * d.inv_count;
+    double var = s2 * d.inv_count - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    const float mean = (float)m;
+    const float invstd = 1.0f / sqrtf((float)(var + (double)d.eps));
+    out[c] = make_float4(mean, r.gamma * invstd, r.beta, invstd);
+    if (upd) {
+        d.saved[2 * c] = mean;
+        d.saved[2 * c + 1] = invstd;
+        const double unb = var * d.unbias;
+        d.rmean[c] = (1.f - d.momentum) * r.rm + d.momentum * mean;
+        d.rvar[c] = (1.f - d.momentum) * r.rv + d.momentum * (float)unb;
+    }
+}
+
+// `first`: the thread that takes channel 0.  A kernel with two descriptors gives the second one to its second wave
+// (first = 64): on one wave the two would be two trips to memory one after the other, the loads of the second behind the
+// wait of the first.
+__device__ __forceinline__ void bn_consts(const BnDesc& d, float4* out, bool designated, int first = 0) {
     if (d.mode == BN_NONE) return;
     // Every consumer's prologue runs this on its critical path, so within a mode every global read is requested before the
     // first wait and before the first store (a store to memory the reads might alias pins the later reads behind it: the
     // sums, then gamma and beta, then the running statistics used to be three to four trips to memory, one after the other).
-    for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+    if (first >= (int)blockDim.x) first = 0;
+    int c_first = (int)threadIdx.x - first;
+    if (c_first < 0) c_first += blockDim.x;
+    for (int c = c_first; c < d.C; c += blockDim.x) {
         float mean, invstd;
-        const float gamma = d.gamma[c];
         if (d.mode == BN_BATCH) {
-            double2 t[kStatShards];
-#pragma unroll
-            for (int sh = 0; sh < kStatShards; sh++) t[sh] = *reinterpret_cast<const double2*>(d.stats + ((size_t)sh * d.C + c) * 4);
-            const float beta = d.beta[c];
             const bool upd = designated && d.update;
-            float rm = 0.f, rv = 0.f;
-            if (upd) {
-                rm = d.rmean[c];
-                rv = d.rvar[c];
-            }
-            double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-            for (int sh = 0; sh < kStatShards; sh++) {
-                s1 += t[sh].x;
-                s2 += t[sh].y;
-            }
-            // multiplications by host-computed reciprocals and an fp32 square root instead of three fp64 divisions and an
-            // fp64 square root
-            const double m = s1 * d.inv_count;
-            double var = s2 * d.inv_count - m * m;
-            var = var < 0.0 ? 0.0 : var;
-            mean = (float)m;
-            invstd = 1.0f / sqrtf((float)(var + (double)d.eps));
-            out[c] = make_float4(mean, gamma * invstd, beta, invstd);
-            if (upd) {
-                d.saved[2 * c] = mean;
-                d.saved[2 * c + 1] = invstd;
-                const double unb = var * d.unbias;
-                d.rmean[c] = (1.f - d.momentum) * rm + d.momentum * mean;
-                d.rvar[c] = (1.f - d.momentum) * rv + d.momentum * (float)unb;
-            }
-        } else if (d.mode == BN_RUNNING) {
+            BnBatchReq rq;
+            bn_batch_request(d, c, upd, rq);
+            bn_batch_finish(d, c, upd, rq, out);
+            continue;
+        }
+        const float gamma = d.gamma[c];
+        if (d.mode == BN_RUNNING) {
             const float beta = d.beta[c];
             mean = d.rmean[c];
             invstd = 1.0f / sqrtf(d.rvar[c] + d.eps);
@@ -342,7 +365,7 @@ __global__ void __launch_bounds__(256) k_down(ConvGeom g, Src big, BnDesc bnb, c
     float4* ce = cb + g.Cl;
     const bool designated = blockIdx.x == 0 && blockIdx.y == 0;
     bn_consts(bnb, cb, designated);
-    bn_consts(bne, ce, false);
+    bn_consts(bne, ce, false, 64);
     // no kernel of the forward/backward pass reads adam_step, so bumping it here cannot race
     if (designated && threadIdx.x == 0 && big.bump_adam) const_cast<StepState*>(st)->adam_step += 1;
     __syncthreads();
@@ -389,7 +412,7 @@ __device__ __forceinline__ void up_body(const ConvGeom& g, const Src& small, con
     float4* ce = cs4 + g.Cs;
     const bool designated = bx == 0 && by == 0;
     bn_consts(bns, cs4, designated);
-    bn_consts(bne, ce, false);
+    bn_consts(bne, ce, false, 64);
     __syncthreads();
 
     const int cl = by;
@@ -507,7 +530,7 @@ __device__ __forceinline__ void wgrad_body(const ConvGeom& g, const Src& small, 
     float4* cs4 = reinterpret_cast<float4*>(lds_d + 4);
     float4* cb = cs4 + g.Cs;
     bn_consts(bns, cs4, false);
-    bn_consts(bnb, cb, false);
+    bn_consts(bnb, cb, false, 64);
     if (bx == 0 && by == 0 && bg.stats) {
         for (int c = threadIdx.x; c < bg.C; c += blockDim.x) {
             double sb = 0.0, sg = 0.0;

@@ -255,7 +255,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
     float4* cprev4 = cout4 + a.Cout;                              // [Cin]
     int2* koff = reinterpret_cast<int2*>(cprev4 + a.Cin);         // [K] {offset of tap k inside one image of gy, its channel}
     bn_consts(a.bn_out, cout4, false);
-    bn_consts(a.bn_prev, cprev4, false);
+    bn_consts(a.bn_prev, cprev4, false, 64);
     for (int k = threadIdx.x; k < K && !(a.KH == 3 && a.KW == 3); k += 256) {   // the 3x3 path below needs no tap table
         const int co = k / (a.KH * a.KW), t = k - co * (a.KH * a.KW);
         const int ky = t / a.KW, kx = t - ky * a.KW;
@@ -450,7 +450,7 @@ __device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, co
     float4* cin4 = reinterpret_cast<float4*>(part + 1024);    // [Cin]
     float4* cout4 = cin4 + a.Cin;                             // [Cout]
     bn_consts(a.bn_in, cin4, false);
-    bn_consts(a.bn_out, cout4, false);
+    bn_consts(a.bn_out, cout4, false, 64);
     if (bx == 0 && by == 0 && a.bg.stats) {
         for (int c = threadIdx.x; c < a.bg.C; c += 256) {
             double sb = 0.0, sg = 0.0;

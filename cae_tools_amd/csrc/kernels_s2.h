@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) k_s2_bwd(S2Bwd a) {
         wl[e] = a.w[(size_t)ci * COUT * KH * KW + tap];
     }
     bn_consts(a.bn_out, cout4, false);
-    bn_consts(a.bn_in, cin4, false);
+    bn_consts(a.bn_in, cin4, false, 64);
     if (blockIdx.x == 0 && a.bg.stats) {
         for (int c = threadIdx.x; c < a.bg.C; c += 256) {
             double sb = 0.0, sg = 0.0;
@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(256) k_s2_bwd2(S2Bwd a) {
     __shared__ float redf[4 * NRED];
 
     bn_consts(a.bn_out, cout4, false);
-    bn_consts(a.bn_in, cin4, false);
+    bn_consts(a.bn_in, cin4, false, 64);
     if (blockIdx.x == 0 && a.bg.stats) {
         for (int c = threadIdx.x; c < a.bg.C; c += 256) {
             double sb = 0.0, sg = 0.0;
@@ -904,7 +904,7 @@ __global__ void __launch_bounds__(256) k_s2_bwd_split(S2Bwd a) {
     __shared__ float redf[4 * NRED];
 
     bn_consts(a.bn_out, cout4, false);
-    bn_consts(a.bn_in, cin4, false);
+    bn_consts(a.bn_in, cin4, false, 64);
     if (blockIdx.x == 0 && a.bg.stats) {
         for (int c = threadIdx.x; c < a.bg.C; c += 256) {
             double sb = 0.0, sg = 0.0;
