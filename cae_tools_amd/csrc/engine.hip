@@ -888,7 +888,8 @@ int dp_finish_step(cae_engine* e, const StepArgs& a) {
     memset(&none, 0, sizeof none);
     ProfScope _p(e, "adam", 0, 28.0 * e->n_param);
     hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
-                       (const float*)e->grads, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(), none, 0);
+                       (const float*)e->grads, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(), none, 0,
+                       std::log(e->hp.beta1), std::log(e->hp.beta2));
     return CAE_OK;
 }
 
@@ -1581,7 +1582,7 @@ int launch_one(cae_engine* e, int op, const StepArgs& a) {
             ProfScope _p(e, "adam", 0, 32.0 * e->n_param);
             hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
                                (const float*)nullptr, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(),
-                               step_tail_of(e, a.inc(), 1), 0);
+                               step_tail_of(e, a.inc(), 1), 0, std::log(e->hp.beta1), std::log(e->hp.beta2));
         } else {
             hipLaunchKernelGGL(k_acc_to_f32, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->grads,
                                e->shard_segs(), step_tail_of(e, a.inc(), 1));
@@ -1596,7 +1597,7 @@ int launch_one(cae_engine* e, int op, const StepArgs& a) {
         // forward_backward already counted this optimiser step (its first kernel bumps adam_step)
         hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
                            (const float*)e->grads, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(),
-                           none, 0);
+                           none, 0, std::log(e->hp.beta1), std::log(e->hp.beta2));
     }
     HIP_TRY(hipGetLastError());
     return CAE_OK;

@@ -779,36 +779,91 @@ __device__ __forceinline__ void step_tail(const StepTail& tl, long long gid, lon
 // over the flat arena.  Gradient source: fp64 accumulators (fused path; consumed and cleared) or
 // the fp32 arena (data-parallel path, after the all-reduce).  st->adam_step is the number of the
 // step being taken (bumped by the first kernel of the step / by cae_adam_step's own bump flag).
+// `ln_b1`, `ln_b2`: natural logarithms of the betas (host).
+// Order matters, this being the one kernel every step ends with: every thread requests its parameter, moments and gradient
+// first; the bias corrections 1 - beta^t = -expm1(t ln beta) are worked out meanwhile by two lanes, one each (the two fp64
+// pow() calls on one lane they replace were a dependent chain of a microsecond ahead of the barrier, with the loads not
+// yet requested behind it).
 __global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p, const float* __restrict__ g32,
                                                float* __restrict__ m, float* __restrict__ v, Hyper h,
-                                               const StepState* __restrict__ st, ShardSegs ss, StepTail tl, int t_add) {
+                                               const StepState* __restrict__ st, ShardSegs ss, StepTail tl, int t_add,
+                                               double ln_b1, double ln_b2) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    // the bias corrections are the same for every element: one lane per workgroup pays for the two fp64 pow()
     __shared__ float corr[2];
-    if (threadIdx.x == 0) {
-        const int t = st->adam_step + t_add;
-        const double bc1 = 1.0 - pow(h.beta1, (double)t);
-        const double bc2 = 1.0 - pow(h.beta2, (double)t);
-        corr[0] = (float)(h.lr / bc1);
-        corr[1] = (float)sqrt(bc2);
+    // The step tail (step_tail's work) first.  No kernel of this step reads the BatchNorm sum tables any more, and nobody in
+    // this kernel reads the cursor: cleared / moved up here, the stores complete in the shadow of the loads below.  Behind
+    // the parameter update they cost a wait of their own: registers are reused there, and the compiler then waits for the
+    // stores ahead of them (the memory counter retires in order).
+    for (long long j = i; j < tl.zero_extra_n; j += (long long)gridDim.x * 256) tl.zero_extra[j] = 0.0;
+    int t = 0;
+    if (threadIdx.x < 2) t = st->adam_step + t_add;
+    const bool moves_cursor = i == 0 && tl.st != nullptr;
+    long long cursor = 0;
+    int slot = 0;
+    if (moves_cursor) {
+        cursor = tl.st->batch_start;
+        slot = tl.st->loss_slot;
+    }
+    const bool mine = i < n;
+    float g = 0.f, w = 0.f, mi = 0.f, vi = 0.f;
+    // the fp64 gradient: its accumulator plus, for a parameter that is accumulated in shards, the eight shard copies.
+    // Requested here, added up behind the barrier, cleared by the kernel's last stores (consume_grad's clearing stores sit
+    // between its loads and their use, and where its paths meet the compiler waits for all but one of them to complete)
+    double gacc = 0.0, sv[kStatShards];
+    double* shp = nullptr;
+    if (mine) {
+        w = p[i];
+        mi = m[i];
+        vi = v[i];
+        if (g32) {
+            g = g32[i];
+        } else {
+            gacc = tl.acc_rw[i];
+            for (int sg = 0; sg < ss.nseg; sg++) {
+                const long long d = i - ss.seg[sg].param_off;
+                if (d >= 0 && d < ss.seg[sg].count) shp = tl.shard_rw + ss.seg[sg].sh_off + d;
+            }
+            if (shp) {
+#pragma unroll
+                for (int sh = 0; sh < kStatShards; sh++) sv[sh] = shp[(size_t)sh * ss.n];
+            }
+        }
+    }
+    if (moves_cursor) {
+        tl.st->batch_start = cursor + tl.batch_inc;
+        tl.st->loss_slot = slot + tl.slot_inc;
+    }
+    if (threadIdx.x < 2) {
+        const double bc = -expm1((double)t * (threadIdx.x ? ln_b2 : ln_b1));
+        corr[threadIdx.x] = threadIdx.x ? (float)sqrt(bc) : (float)(h.lr / bc);
     }
     __syncthreads();
-    if (tl.zero_extra || tl.st) step_tail(tl, i, (long long)gridDim.x * 256);
-    if (i >= n) return;
-    const float step_size = corr[0];
-    const float bc2_sqrt = corr[1];
-    const float b1 = (float)h.beta1, b2 = (float)h.beta2;
-    float g = g32 ? g32[i] : consume_grad(tl, ss, i);
-    const float w = p[i];
-    if (h.wd != 0.0) g = fmaf((float)h.wd, w, g);
-    float mi = m[i], vi = v[i];
-    mi = mi + (g - mi) * (float)(1.0 - h.beta1);
-    vi = vi * b2 + ((float)(1.0 - h.beta2) * g) * g;
-    const float denom = sqrtf(vi) / bc2_sqrt + (float)h.eps;
-    p[i] = w - step_size * (mi / denom);
-    m[i] = mi;
-    v[i] = vi;
-    (void)b1;
+    if (mine) {
+        const float step_size = corr[0];
+        const float bc2_sqrt = corr[1];
+        const float b2 = (float)h.beta2;
+        if (!g32) {
+            if (shp) {
+#pragma unroll
+                for (int sh = 0; sh < kStatShards; sh++) gacc += sv[sh];
+            }
+            g = (float)gacc;
+        }
+        if (h.wd != 0.0) g = fmaf((float)h.wd, w, g);
+        mi = mi + (g - mi) * (float)(1.0 - h.beta1);
+        vi = vi * b2 + ((float)(1.0 - h.beta2) * g) * g;
+        const float denom = sqrtf(vi) / bc2_sqrt + (float)h.eps;
+        p[i] = w - step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+        if (!g32) {
+            tl.acc_rw[i] = 0.0;
+            if (shp) {
+#pragma unroll
+                for (int sh = 0; sh < kStatShards; sh++) shp[(size_t)sh * ss.n] = 0.0;
+            }
+        }
+    }
 }
 
 __global__ void k_acc_to_f32(long long n, float* __restrict__ g, ShardSegs ss, StepTail tl) {
