@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(512) k_ct_fwd_lds(CtFwd a) {
     const int qy = div_small(qic, inv_qw), qx = qic - qy * a.QW;
     const int cper = a.Cin / a.ks, c0 = kslot * cper;            // host: cper % 4 == 0
     const int co = cb * 16 + r;
-    const float bias = a.bias[min(co, a.Cout - 1)];              // requested before the loop, used after it
+    float bias = a.bias[min(co, a.Cout - 1)];                    // requested before the loop, used after it
 
     f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
     if (tile_ok) {
@@ -240,6 +240,11 @@ __global__ void __launch_bounds__(512) k_ct_fwd_lds(CtFwd a) {
         }
     }
     CT_STAMP(3);
+    // The bias is waited for HERE, once, outside the predicated stores below.  Left to its first use - inside a predicated
+    // block, which the lanes that skip it leave with the load still formally pending - the compiler repeats the wait in every
+    // one of the sixteen blocks, and from the second on that wait is for the previous block's STORE to complete (the memory
+    // counter retires in order): sixteen store round trips one after the other.
+    asm volatile("" : "+v"(bias));
 
     // Epilogue.  Register `reg` = 4 * parity + jj of lane (q, r) is quad row 4q + jj of the tile, output channel r.
     float s1 = 0.f, s2 = 0.f;

@@ -366,6 +366,10 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
             for (int u = 0; u < kIgdSteps; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
         }
         IGD_STAMP(2);
+        // the epilogue inputs are waited for here, once, outside the predicated stores below (left to their first use inside
+        // a predicated block, the wait is repeated per block and, the memory counter retiring in order, becomes a wait for
+        // the previous block's store to complete: four store round trips one after the other)
+        asm volatile("" : "+v"(yp[0]), "+v"(yp[1]), "+v"(yp[2]), "+v"(yp[3]));
         if (KS > 1) {
             __syncthreads();
 #pragma unroll
