@@ -723,6 +723,14 @@ bool head_plan(const cae_engine* e, const StepArgs& a, HeadArgs& h, size_t& lds_
         wf += 64;   // k-batches read past the last row
         h.w_total4 = start4;
         if (h.w_total4 > kHeadW4 * kHeadThreads) return false;
+        for (int j = 0; j < kHeadW4; j++) {
+            const int lo = j * kHeadThreads, hi = std::min((j + 1) * kHeadThreads, h.w_total4) - 1;   // float4s of piece j
+            h.piece_m[j] = -1;
+            for (int m = 0; m < 4 && hi >= lo; m++) {
+                const int mend = m < 3 ? h.wmat[m + 1].start4 : h.w_total4;
+                if (lo >= h.wmat[m].start4 && hi < mend) h.piece_m[j] = m;
+            }
+        }
         int64_t ef = (int64_t)a.batch * e->enc[0].in_elems();
         for (int l = 0; l + 1 < h.n_enc; l++) ef += align_up((int64_t)a.batch * e->enc[l].out_elems(), 4);
         const int base = take(std::max(wf, ef));

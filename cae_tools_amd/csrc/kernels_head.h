@@ -87,6 +87,7 @@ struct HeadArgs {
     StageSplit fc_split[4];
     HeadW wmat[4];      // head: Linear weights (Linear 3: this workgroup's strip of rows) copied to LDS after the encoder
     int w_total4;       // float4s over the four matrices
+    int piece_m[kHeadW4];   // matrix that holds ALL of piece j (float4s [j, j + 1) * kHeadThreads), or -1 when it straddles two
     int n_seg;          // head: small read-only vectors copied to LDS in one burst (<= 1024 floats each)
     HeadSeg seg[kHeadMaxSeg];
     long long* dbg;     // diagnostics (tools/head_phases.py): per workgroup 16 wall-clock stamps, or nullptr
@@ -307,6 +308,61 @@ __device__ __forceinline__ void head_encoder(const HeadArgs& a, float* lds, bool
 #pragma unroll
             for (int j = 0; j < 4; j++) cj[j] = min(c0 + j, L.cout - 1);
             double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+            if (k3 && L.cin == 1) {
+                // the first layer (one input channel, several positions per thread): the 36 weights of the four output
+                // channels are read once, ahead of the position loop - per position their LDS reads outnumbered the taps'
+                // four to one - and the sums stay in fp32 for four positions at a time before they are folded into the
+                // fp64 running sums (this phase is bound by instruction issue: one workgroup computes the whole batch)
+                float w[4][9];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int i = 0; i < 9; i++) w[j][i] = wl[cj[j] * 9 + i];
+                float bj[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) bj[j] = bl[cj[j]];
+                float p1[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};
+                int pass = 0;
+                for (int idx = tid; idx < npos; idx += kHeadThreads, pass++) {
+                    const int b = div_small(idx, inv_hw), r = idx - b * hw;
+                    const int y = div_small(r, inv_w), x = r - y * L.wout;
+                    const float* ip = yin + b * ihw + (y * L.s) * L.win + x * L.s;
+                    float v[9];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) v[ky * 3 + kx] = ip[ky * L.win + kx];
+                    if (l) {
+                        const float4 kb = kin[0];
+#pragma unroll
+                        for (int i = 0; i < 9; i++) v[i] = fmaxf(0.f, fmaf(v[i] - kb.x, kb.y, kb.z));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float acc = bj[j];
+#pragma unroll
+                        for (int i = 0; i < 9; i++) acc = fmaf(v[i], w[j][i], acc);
+                        if (c0 + j < L.cout) {
+                            yout[(b * L.cout + c0 + j) * hw + r] = acc;
+                            p1[j] += acc;
+                            p2[j] = fmaf(acc, acc, p2[j]);
+                        }
+                    }
+                    if ((pass & 3) == 3) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            s1[j] += (double)p1[j];
+                            s2[j] += (double)p2[j];
+                            p1[j] = p2[j] = 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    s1[j] += (double)p1[j];
+                    s2[j] += (double)p2[j];
+                }
+            } else
             for (int idx = tid; idx < npos; idx += kHeadThreads) {
                 const int b = div_small(idx, inv_hw), r = idx - b * hw;
                 const int y = div_small(r, inv_w), x = r - y * L.wout;
@@ -366,23 +422,26 @@ __device__ __forceinline__ void head_encoder(const HeadArgs& a, float* lds, bool
         if (l < 2) head_stamp(a, 9 + 3 * l);
         __syncthreads();
         float4* kout = reinterpret_cast<float4*>(lds + L.o_c);
-        if (tid < L.cout) {
-            const int c = tid;
+        // a row of 16 lanes per channel: each lane takes one wave's partial sums, the row adds them up with DPP (one thread
+        // per channel walking the 16 partials was 32 dependent LDS reads: a microsecond per layer)
+        static_assert(kHeadWaves == 16, "one DPP row per channel");
+        if (tid < L.cout * 16) {
+            const int c = tid >> 4;
             const float gamma = lds[L.o_gamma + c], beta = lds[L.o_beta + c], rm = lds[L.o_rm + c], rv = lds[L.o_rv + c];
             float mean, invstd;
             if (a.train) {
-                double t1 = 0.0, t2 = 0.0;
-                for (int w = 0; w < kHeadWaves; w++) {
-                    t1 += red[(c * kHeadWaves + w) * 2];
-                    t2 += red[(c * kHeadWaves + w) * 2 + 1];
-                }
+                double t1 = red[tid * 2], t2 = red[tid * 2 + 1];   // [(c * kHeadWaves + wave) * 2]
+                t1 += dpp_d<0xB1>(t1);  t2 += dpp_d<0xB1>(t2);
+                t1 += dpp_d<0x4E>(t1);  t2 += dpp_d<0x4E>(t2);
+                t1 += dpp_d<0x141>(t1); t2 += dpp_d<0x141>(t2);
+                t1 += dpp_d<0x140>(t1); t2 += dpp_d<0x140>(t2);   // every lane of the row holds the row's sum
                 const double inv_count = L.inv_count;   // host-computed 1 / (B * hout * wout): no fp64 divisions here
                 const double m = t1 * inv_count;
                 double var = t2 * inv_count - m * m;
                 var = var < 0.0 ? 0.0 : var;
                 mean = (float)m;
                 invstd = 1.0f / sqrtf((float)(var + (double)a.eps));
-                if (publish) {
+                if (publish && (tid & 15) == 0) {
                     L.saved[2 * c] = mean;
                     L.saved[2 * c + 1] = invstd;
                     const double unb = var * L.unbias;   // count / (count - 1), or 1 for a single element
@@ -393,7 +452,7 @@ __device__ __forceinline__ void head_encoder(const HeadArgs& a, float* lds, bool
                 mean = rm;
                 invstd = 1.0f / sqrtf(rv + a.eps);
             }
-            kout[c] = make_float4(mean, gamma * invstd, beta, invstd);
+            if ((tid & 15) == 0) kout[c] = make_float4(mean, gamma * invstd, beta, invstd);
         }
         if (publish && a.train)
             for (int i = tid; i < npos * L.cout; i += kHeadThreads) L.y[i] = yout[i];
@@ -435,17 +494,34 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(HeadArgs a) {
     // kernel.  The rest - the tail of the piece order, i.e. the last Linear layer's - is requested after the encoder and
     // lands behind the first Linear layer.
     const int st1 = a.wmat[1].start4, st2 = a.wmat[2].start4, st3 = a.wmat[3].start4;
+    // (a piece that lies inside one matrix - the host says which - takes that matrix's descriptor through scalar registers;
+    // only a straddling piece pays for the per-lane selects)
     auto load_piece = [&](int j) {
+        const int idx = min(tid + j * kHeadThreads, a.w_total4 - 1);
+        const int pm = a.piece_m[j];
+        if (pm >= 0) {
+            const HeadW& w = a.wmat[pm];
+            return (reinterpret_cast<const f32x4*>(w.src + (size_t)blockIdx.y * w.strip_floats) - w.start4)[idx];
+        }
         const f32x4* wsrc[4];
 #pragma unroll
         for (int m = 0; m < 4; m++)
             wsrc[m] = reinterpret_cast<const f32x4*>(a.wmat[m].src + (size_t)blockIdx.y * a.wmat[m].strip_floats) - a.wmat[m].start4;
-        const int idx = min(tid + j * kHeadThreads, a.w_total4 - 1);
         const f32x4* src = idx >= st3 ? wsrc[3] : idx >= st2 ? wsrc[2] : idx >= st1 ? wsrc[1] : wsrc[0];
         return src[idx];
     };
     auto store_piece = [&](int j, const f32x4& val) {
         const int idx = tid + j * kHeadThreads;
+        const int pm = a.piece_m[j];
+        if (pm >= 0) {
+            const HeadW& w = a.wmat[pm];
+            if (idx < a.w_total4) {
+                const int local = idx - w.start4;
+                const int row = div_small(local, 1.0f / (float)w.n4row);
+                *reinterpret_cast<f32x4*>(lds + w.lds_off + row * w.ldw + 4 * (local - row * w.n4row)) = val;
+            }
+            return;
+        }
         if (idx < a.w_total4) {
             const bool m3 = idx >= st3, m2 = idx >= st2, m1 = idx >= st1;
             auto pick = [&](int v0, int v1, int v2, int v3) { return m3 ? v3 : m2 ? v2 : m1 ? v1 : v0; };
