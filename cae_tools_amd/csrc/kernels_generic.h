@@ -286,8 +286,9 @@ __device__ __forceinline__ size_t sample_of(const int* perm, int use_cursor, con
 // ---------------------------------------------------------------------------------------------
 // shared epilogue: thread-level part returns the two values to be block-reduced
 // ---------------------------------------------------------------------------------------------
+// `ypre` (with have_ypre): the caller already holds e.yprev[o] (EPI_MASKSTATS), requested ahead of its main loop
 __device__ __forceinline__ void epi_element(const Epi& e, const float4* ce, int c, size_t o, size_t tgt_off,
-                                             float acc, double& r1, double& r2) {
+                                             float acc, double& r1, double& r2, bool have_ypre = false, float ypre = 0.f) {
     switch (e.kind) {
         case EPI_PLAIN:
             e.out[o] = acc;
@@ -299,7 +300,7 @@ __device__ __forceinline__ void epi_element(const Epi& e, const float4* ce, int 
             break;
         case EPI_MASKSTATS: {
             const float4 k = ce[c];
-            const float yv = e.yprev[o];
+            const float yv = have_ypre ? ypre : e.yprev[o];
             const float d = yv - k.x;
             const float a = fmaf(d, k.y, k.z);
             const float g = a > 0.f ? acc : 0.f;
@@ -411,56 +412,86 @@ __device__ __forceinline__ void up_body(const ConvGeom& g, const Src& small, con
     float4* cs4 = reinterpret_cast<float4*>(lds_d + 4);
     float4* ce = cs4 + g.Cs;
     const bool designated = bx == 0 && by == 0;
-    bn_consts(bns, cs4, designated);
-    bn_consts(bne, ce, false, 64);
-    __syncthreads();
 
     const int cl = by;
     const int hw = g.Hl * g.Wl;
     const int n = g.B * hw;
     const int idx = bx * 256 + threadIdx.x;
-    double r1 = 0, r2 = 0;
-    if (idx < n) {
-        const int b = idx / hw, r = idx - b * hw;
-        const int Y = r / g.Wl, X = r - Y * g.Wl;
-        const size_t sb = sample_of(small.perm, small.use_cursor, st, b);
-        float acc = bias ? bias[cl] : 0.f;
-        // taps of output (Y, X): ky = Y mod s, + s, ... reading row y = Y / s, - 1, ...: one division per dimension per
-        // thread instead of one per (channel, tap)
-        const int y0 = Y / g.s, x0 = X / g.s;
-        const int ky0 = Y - y0 * g.s, kx0 = X - x0 * g.s;
-        if (g.kh <= 2 * g.s && g.kw <= 2 * g.s) {
-            // At most 2 x 2 taps per output (3x3 or 4x4 kernels at stride 2).  The general loop below issues one load, waits,
-            // multiplies, per (channel, tap): ~16 dependent memory round trips per thread.  Here four channels' taps, their
-            // raw outputs (BatchNorm backward) and weights are fetched together from clamped addresses, then consumed in
-            // the same (channel, ky, kx) order.
-            int yy[2], xx[2], kyy[2], kxx[2];
-            bool vy[2], vx[2];
+    const bool mine = idx < n;
+    const int ic = mine ? idx : 0;
+    const int b = ic / hw, r = ic - b * hw;
+    const int Y = r / g.Wl, X = r - Y * g.Wl;
+    const size_t o = ((size_t)(b * g.Cl + cl) * g.Hl + Y) * g.Wl + X;
+    // taps of output (Y, X): ky = Y mod s, + s, ... reading row y = Y / s, - 1, ...: one division per dimension per
+    // thread instead of one per (channel, tap)
+    const int y0 = Y / g.s, x0 = X / g.s;
+    const int ky0 = Y - y0 * g.s, kx0 = X - x0 * g.s;
+    // At most 2 x 2 taps per output (3x3 or 4x4 kernels at stride 2).  The general loop further down issues one load, waits,
+    // multiplies, per (channel, tap): ~16 dependent memory round trips per thread.  Here four channels' taps, their raw
+    // outputs (BatchNorm backward) and weights are fetched together from clamped addresses, then consumed in the same
+    // (channel, ky, kx) order.
+    const bool four_taps = g.kh <= 2 * g.s && g.kw <= 2 * g.s;
+    int yy[2], xx[2], kyy[2], kxx[2];
+    bool vy[2], vx[2];
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int ky = ky0 + t * g.s, y = y0 - t, kx = kx0 + t * g.s, x = x0 - t;
-                vy[t] = ky < g.kh && y >= 0 && y < g.Hs;
-                vx[t] = kx < g.kw && x >= 0 && x < g.Ws;
-                yy[t] = min(max(y, 0), g.Hs - 1);
-                xx[t] = min(max(x, 0), g.Ws - 1);
-                kyy[t] = min(ky, g.kh - 1);
-                kxx[t] = min(kx, g.kw - 1);
+    for (int t = 0; t < 2; t++) {
+        const int ky = ky0 + t * g.s, y = y0 - t, kx = kx0 + t * g.s, x = x0 - t;
+        vy[t] = ky < g.kh && y >= 0 && y < g.Hs;
+        vx[t] = kx < g.kw && x >= 0 && x < g.Ws;
+        yy[t] = min(max(y, 0), g.Hs - 1);
+        xx[t] = min(max(x, 0), g.Ws - 1);
+        kyy[t] = min(ky, g.kh - 1);
+        kxx[t] = min(kx, g.kw - 1);
+    }
+    const int khw = g.kh * g.kw;
+    size_t sb = 0;
+    auto load_group = [&](int c0, float (&gv)[4][4], float (&qv)[4][4], float (&wv)[4][4]) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int cs = min(c0 + c, g.Cs - 1);
+            const float* wp = w + (size_t)(cs * g.Cl + cl) * khw;
+            const size_t base = (sb * g.Cs + cs) * (size_t)g.Hs * g.Ws;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const size_t off = base + (size_t)yy[t >> 1] * g.Ws + xx[t & 1];
+                gv[c][t] = small.p[off];
+                qv[c][t] = bns.mode == BN_BWD ? small.q[off] : 0.f;
+                wv[c][t] = wp[kyy[t >> 1] * g.kw + kxx[t & 1]];
             }
-            const int khw = g.kh * g.kw;
+        }
+    };
+    // The first group of four channels and the epilogue's mask input are requested before the BatchNorm constants are worked
+    // out (their sums, the barrier): one trip to memory for all of it instead of three in a row.
+    float gv0[4][4], qv0[4][4], wv0[4][4];
+    float ypre = 0.f;
+    const bool pre_mask = e.kind == EPI_MASKSTATS;
+    if (mine) {
+        sb = sample_of(small.perm, small.use_cursor, st, b);
+        if (four_taps) load_group(0, gv0, qv0, wv0);
+        if (pre_mask) ypre = e.yprev[o];
+    }
+
+    bn_consts(bns, cs4, designated);
+    bn_consts(bne, ce, false, 64);
+    __syncthreads();
+
+    double r1 = 0, r2 = 0;
+    if (mine) {
+        float acc = bias ? bias[cl] : 0.f;
+        if (four_taps) {
             for (int c0 = 0; c0 < g.Cs; c0 += 4) {
                 float gv[4][4], qv[4][4], wv[4][4];
+                if (c0 == 0) {
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int cs = min(c0 + c, g.Cs - 1);
-                    const float* wp = w + (size_t)(cs * g.Cl + cl) * khw;
-                    const size_t base = (sb * g.Cs + cs) * (size_t)g.Hs * g.Ws;
+                    for (int c = 0; c < 4; c++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const size_t off = base + (size_t)yy[t >> 1] * g.Ws + xx[t & 1];
-                        gv[c][t] = small.p[off];
-                        qv[c][t] = bns.mode == BN_BWD ? small.q[off] : 0.f;
-                        wv[c][t] = wp[kyy[t >> 1] * g.kw + kxx[t & 1]];
-                    }
+                        for (int t = 0; t < 4; t++) {
+                            gv[c][t] = gv0[c][t];
+                            qv[c][t] = qv0[c][t];
+                            wv[c][t] = wv0[c][t];
+                        }
+                } else {
+                    load_group(c0, gv, qv, wv);
                 }
 #pragma unroll
                 for (int c = 0; c < 4; c++)
@@ -491,13 +522,12 @@ __device__ __forceinline__ void up_body(const ConvGeom& g, const Src& small, con
                 }
             }
         }
-        const size_t o = ((size_t)(b * g.Cl + cl) * g.Hl + Y) * g.Wl + X;
         size_t tgt = 0;
         if (e.kind >= EPI_SIGMSE && e.target) {
             const size_t tb = sample_of(e.perm, e.use_cursor, st, b);
             tgt = ((tb * g.Cl + cl) * (size_t)g.Hl + Y) * g.Wl + X;
         }
-        epi_element(e, ce, cl, o, tgt, acc, r1, r2);
+        epi_element(e, ce, cl, o, tgt, acc, r1, r2, pre_mask, ypre);
     }
     epi_block(e, cl, st, r1, r2, red, bx);
 }
@@ -529,6 +559,48 @@ __device__ __forceinline__ void wgrad_body(const ConvGeom& g, const Src& small, 
     double* red = lds_d;
     float4* cs4 = reinterpret_cast<float4*>(lds_d + 4);
     float4* cb = cs4 + g.Cs;
+
+    int widx = bx;
+    const int kx = widx % g.kw;
+    widx /= g.kw;
+    const int ky = widx % g.kh;
+    widx /= g.kh;
+    const int cl = widx % g.Cl;
+    const int cs = widx / g.Cl;
+    const int hw = g.Hs * g.Ws;
+    const long long n = (long long)g.B * hw;
+    const long long p0 = (long long)by * ppb;
+    long long p1 = p0 + ppb;
+    if (p1 > n) p1 = n;
+    const bool fastdiv = n < kDivSmallMaxN && hw < kDivSmallMaxD;   // 3-instruction index arithmetic instead of 64-bit divisions
+    const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)g.Ws;
+    // raw operands of position p (the BatchNorm transforms are applied by the caller)
+    auto fetch = [&](long long p, float& sp, float& sq, float& lp, float& lq) {
+        int b, y;
+        if (fastdiv) {
+            b = div_small((int)p, inv_hw);
+            y = div_small((int)p - b * hw, inv_w);
+        } else {
+            b = (int)(p / hw);
+            y = (int)(p - (long long)b * hw) / g.Ws;
+        }
+        const int r = (int)(p - (long long)b * hw), x = r - y * g.Ws;
+        const size_t ss = sample_of(small.perm, small.use_cursor, st, b);
+        const size_t sl = sample_of(big.perm, big.use_cursor, st, b);
+        const size_t so = ((ss * g.Cs + cs) * (size_t)g.Hs + y) * g.Ws + x;
+        const size_t lo = ((sl * g.Cl + cl) * (size_t)g.Hl + (size_t)(y * g.s + ky)) * g.Wl + (size_t)x * g.s + kx;
+        sp = small.p[so];
+        sq = bns.mode == BN_BWD ? small.q[so] : 0.f;
+        lp = big.p[lo];
+        lq = bnb.mode == BN_BWD ? big.q[lo] : 0.f;
+    };
+    // The first position's operands are requested before the BatchNorm constants are worked out: with the usual one
+    // position per thread (wgrad_ppb) the kernel is then one trip to memory deep instead of two (cursor -> operands used to
+    // start behind the constants' sums and the barrier).
+    const long long pf = p0 + threadIdx.x;
+    float f_sp = 0.f, f_sq = 0.f, f_lp = 0.f, f_lq = 0.f;
+    if (pf < p1) fetch(pf, f_sp, f_sq, f_lp, f_lq);
+
     bn_consts(bns, cs4, false);
     bn_consts(bnb, cb, false, 64);
     if (bx == 0 && by == 0 && bg.stats) {
@@ -543,42 +615,15 @@ __device__ __forceinline__ void wgrad_body(const ConvGeom& g, const Src& small, 
         }
     }
     __syncthreads();
-
-    int widx = bx;
-    const int kx = widx % g.kw;
-    widx /= g.kw;
-    const int ky = widx % g.kh;
-    widx /= g.kh;
-    const int cl = widx % g.Cl;
-    const int cs = widx / g.Cl;
     const float4 ks = bns.mode ? cs4[cs] : make_float4(0, 0, 0, 0);
     const float4 kb = bnb.mode ? cb[cl] : make_float4(0, 0, 0, 0);
 
-    const int hw = g.Hs * g.Ws;
-    const long long n = (long long)g.B * hw;
-    const long long p0 = (long long)by * ppb;
-    long long p1 = p0 + ppb;
-    if (p1 > n) p1 = n;
     float sum = 0.f;
-    const bool fastdiv = n < kDivSmallMaxN && hw < kDivSmallMaxD;   // 3-instruction index arithmetic instead of 64-bit divisions
-    const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)g.Ws;
-    for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
-        int b, y;
-        if (fastdiv) {
-            b = div_small((int)p, inv_hw);
-            y = div_small((int)p - b * hw, inv_w);
-        } else {
-            b = (int)(p / hw);
-            y = (int)(p - (long long)b * hw) / g.Ws;
-        }
-        const int r = (int)(p - (long long)b * hw), x = r - y * g.Ws;
-        const size_t ss = sample_of(small.perm, small.use_cursor, st, b);
-        const size_t sl = sample_of(big.perm, big.use_cursor, st, b);
-        const size_t so = ((ss * g.Cs + cs) * (size_t)g.Hs + y) * g.Ws + x;
-        const size_t lo = ((sl * g.Cl + cl) * (size_t)g.Hl + (size_t)(y * g.s + ky)) * g.Wl + (size_t)x * g.s + kx;
-        const float sv = bn_apply(bns.mode, ks, small.p[so], bns.mode == BN_BWD ? small.q[so] : 0.f);
-        const float lv = bn_apply(bnb.mode, kb, big.p[lo], bnb.mode == BN_BWD ? big.q[lo] : 0.f);
-        sum = fmaf(sv, lv, sum);
+    if (pf < p1) sum = bn_apply(bns.mode, ks, f_sp, f_sq) * bn_apply(bnb.mode, kb, f_lp, f_lq);
+    for (long long p = pf + 256; p < p1; p += 256) {
+        float sp, sq, lp, lq;
+        fetch(p, sp, sq, lp, lq);
+        sum = fmaf(bn_apply(bns.mode, ks, sp, sq), bn_apply(bnb.mode, kb, lp, lq), sum);
     }
     const double t = block_sum((double)sum, red);
     if (threadIdx.x == 0) atomicAdd(&acc[bx], t);
