@@ -21,6 +21,7 @@
 #include "kernels_gemm.h"
 #include "kernels_igemm.h"
 #include "kernels_ctlds.h"
+#include "kernels_ctbwd.h"
 #include "kernels_head.h"
 #include "dp_comm.h"
 
@@ -111,6 +112,7 @@ struct cae_engine {
     int64_t ds_n[2] = {0, 0};
     bool graph_mode = true;
     bool use_s2 = true;  // specialised stride-2 kernels (cae_set_kernel_mode)
+    int ctbwd_mask = 0;  // bit l: decoder layer l's backward runs the LDS-staged kernel (kernels_ctbwd.h) where eligible
     // profiling (cae_profile_begin/end): every launch bracketed by an event pair, plain launches
     bool profiling = false;
     struct ProfRec { const char* name; int layer; double bytes; hipEvent_t e0, e1; };
@@ -1254,6 +1256,61 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             continue;
         }
         if (e->use_s2) {
+            // LDS-staged backward (kernels_ctbwd.h): 3x3 kernels at stride 2, whole 16-channel blocks, images that fit the
+            // staging registers / LDS, and few enough images per accumulator address; otherwise the gather pair below
+            if (l < 31 && ((e->ctbwd_mask >> l) & 1) && L.kh == 3 && L.kw == 3 && L.stride == 2 && L.cin % 16 == 0 && L.cout % 4 == 0 &&
+                L.hout >= 2 * L.hin + 1 && L.wout >= 2 * L.win + 1) {
+                const int HW = L.hin * L.win, OHW = L.hout * L.wout, N = L.cout * 9;
+                int budget = std::min((4 * kCtbG4 * kCtbThreads) / (L.cout * OHW), (4 * kCtbA4 * kCtbThreads) / (16 * HW));
+                int imgs = (int)(((int64_t)L.cin * N * B + 149999) / 150000);
+                imgs = std::max(1, std::min(std::min(imgs, budget), B));
+                const int groups = (B + imgs - 1) / imgs;
+                const int wstr = N | 1;
+                const size_t lds = ct_bwd_lds_bytes(L.cin, L.cout, imgs, HW, OHW, wstr);
+                if (budget >= 1 && 16 * N <= 4 * kCtbW4 * kCtbThreads && lds <= 152 * 1024 &&
+                    (int64_t)L.cin * N * groups <= 400000) {
+                    CtBwd c;
+                    memset(&c, 0, sizeof c);
+                    c.B = B; c.Cin = L.cin; c.H = L.hin; c.W = L.win; c.Cout = L.cout; c.OH = L.hout; c.OW = L.wout;
+                    c.imgs = imgs; c.wstr = wstr;
+                    c.g = gy.p; c.yout = gy.q; c.bn_out = bng;
+                    c.ain = ain.p; c.bn_in = bna;
+                    c.w = e->params + L.w_off;
+                    if (L.sh_w >= 0) {
+                        c.wacc = e->sgacc() + L.sh_w;
+                        c.wacc_stride = e->segs.n;
+                    } else {
+                        c.wacc = acc + L.w_off;
+                    }
+                    if (l == 0) {
+                        c.gin = e->fptr(e->fc[3].grad_off);
+                    } else {
+                        const ConvLayer& P = e->dec[l - 1];
+                        c.gin = e->fptr(P.grad_off);
+                        c.stats_prev = e->bn_stats(P.bn_index);
+                    }
+                    if (L.has_bn) {
+                        c.bg.stats = e->bn_stats(L.bn_index);
+                        c.bg.gamma_acc = acc + L.gamma_off;
+                        c.bg.beta_acc = acc + L.beta_off;
+                        c.bg.C = L.cout;
+                        c.bg.scale = 1.0 / a.world;
+                    }
+                    {
+                        static const int dbg = env_int("CAE_HEAD_DBG", 0), dbg_layer = env_int("CAE_DBG_LAYER", 2);   // tools/last_phases.py ctb
+                        c.dbg = dbg == 6 && l == dbg_layer ? reinterpret_cast<long long*>(e->ws + e->off_scan) : nullptr;
+                    }
+                    ProfScope _p(e, "ct_convt_bwd", l,
+                                 f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));
+                    head_lds_attr(k_ct_bwd_lds, lds);
+                    static const int wg_target = env_int("CAE_CTBWD_WGS", 256);   // env: tuning only
+                    const int parts = std::max(1, std::min(8, wg_target / (groups * (L.cin / 16))));
+                    hipLaunchKernelGGL(k_ct_bwd_lds, dim3((unsigned)groups, (unsigned)(L.cin / 16), (unsigned)parts), dim3(kCtbThreads), lds, s, c);
+                    if (l > 0)
+                        if (int rc = sync_bn_table(e, a, e->dec[l - 1].bn_index)) return rc;
+                    continue;
+                }
+            }
             IgWgrad fw;
             memset(&fw, 0, sizeof fw);
             fw.B = B; fw.Cin = L.cin; fw.H = L.hin; fw.W = L.win; fw.Cout = L.cout; fw.OH = L.hout; fw.OW = L.wout;
@@ -1771,7 +1828,14 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
         int n = 0;
         for (size_t l = 0; l < e->dec.size(); l++) {
             ConvLayer& L = e->dec[l];
-            if (!s2_shape_ok(L) || e->segs.nseg + 2 > 12) continue;
+            // (... and the layers of the LDS-staged backward kernel, kernels_ctbwd.h: its workgroups all reach their weight-
+            // gradient atomics at the same moment, one per image group and address; unsharded they queue up behind the
+            // kernel's end - measured 8 us of a 16 us launch at the benchmark's third layer)
+            static const int ctb_env = env_int("CAE_CTBWD", 0);   // env: bit l = decoder layer l on the LDS-staged backward kernel
+            if (l == 0) e->ctbwd_mask = ctb_env;
+            const bool ctb = l < 31 && ((ctb_env >> l) & 1) && L.transposed && L.stride == 2 && L.kh == 3 && L.kw == 3 &&
+                             L.cin % 16 == 0 && L.cout % 4 == 0;
+            if ((!s2_shape_ok(L) && !ctb) || e->segs.nseg + 2 > 12) continue;
             const int nw = L.cin * L.cout * L.kh * L.kw;
             L.sh_w = n;
             e->segs.seg[e->segs.nseg++] = ShardSeg{L.w_off, nw, n};
@@ -1888,8 +1952,11 @@ int cae_set_graph_mode(cae_engine* e, int enabled) {
 
 int cae_set_kernel_mode(cae_engine* e, int specialised) {
     if (!e) return fail(CAE_ERR_ARG, "null engine");
-    if (e->use_s2 != (specialised != 0)) e->drop_graphs();
-    e->use_s2 = specialised != 0;
+    static const int ctb_env = env_int("CAE_CTBWD", 0);   // a mask given by the environment at creation stays as it is
+    const int ctb = ctb_env ? ctb_env : ((specialised & 2) ? 0x7fffffff : 0);
+    if (e->use_s2 != ((specialised & 1) != 0) || ctb != e->ctbwd_mask) e->drop_graphs();
+    e->use_s2 = (specialised & 1) != 0;
+    e->ctbwd_mask = ctb;
     return CAE_OK;
 }
 

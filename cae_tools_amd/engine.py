@@ -97,7 +97,7 @@ class HipEngine(EnginePlan):
                                 ws_ptr, self.workspace_bytes))
         check(self.lib.cae_set_stream(self.handle, self.stream.cuda_stream))
         check(self.lib.cae_set_graph_mode(self.handle, 1 if graph else 0))
-        check(self.lib.cae_set_kernel_mode(self.handle, 1 if specialised else 0))
+        check(self.lib.cae_set_kernel_mode(self.handle, int(specialised) if isinstance(specialised, int) and not isinstance(specialised, bool) else (1 if specialised else 0)))
         torch.cuda.synchronize(self.device)
         self.num_batches_tracked = 0
         self.adam_steps = 0

@@ -120,3 +120,47 @@ def test_other_geometries_of_the_row_and_fused_kernels(in_size, out_size, batch)
     labels = {name for (name, layer, us, nbytes) in eng.profile_end()}
     assert "s2_convt_last_fused" in labels, labels
     assert "s2_convt_bwd" in labels and "s2_convt_fwd" in labels, labels
+
+
+@pytest.mark.parametrize("batch", [64, 5])
+def test_lds_staged_backward_alternative(batch):
+    """kernels_ctbwd.h (cae_set_kernel_mode bit 1): the LDS-staged input-gradient + weight-gradient kernel of the channel-rich
+    decoder layers, kept beside the gather pair it does not beat.  Same bar as the default path: loss and every gradient of
+    one training step at the benchmark geometry against the CPU oracle; batch 5 leaves the last image group short (8 images
+    per workgroup at the first layer) and the last 16-position tile of every layer ragged."""
+    from cae_tools_amd.engine import HipEngine
+    from cae_tools_amd.models.model_sizer import create_model_spec
+    from cae_tools_amd.models.encoder import Encoder
+    from cae_tools_amd.models.decoder import Decoder
+    from oracle import cae_oracle as orc
+    from helpers import bn_bias_keys
+    torch.set_num_threads(8)
+    spec = create_model_spec(input_size=(16, 16), input_channels=1, output_size=(256, 256), output_channels=1)
+    torch.manual_seed(23)
+    enc = Encoder(spec.get_input_layers(), encoded_space_dim=32, fc_size=128)
+    dec = Decoder(spec.get_output_layers(), encoded_space_dim=32, fc_size=128)
+    g = torch.Generator().manual_seed(24)
+    x = torch.rand((batch, 1, 16, 16), generator=g)
+    t = torch.rand((batch, 1, 256, 256), generator=g)
+    eng = HipEngine(spec, 128, 32, max_batch=64, specialised=3)
+    eng.load_state(enc.state_dict(), dec.state_dict())
+    eng.set_hyper(lr=1e-3, weight_decay=1e-5)
+    eng.set_dataset(0, x.cuda(), t.cuda())
+    ref = orc.OracleModel(spec.save(), enc.state_dict(), dec.state_dict(), lr=1e-3, weight_decay=1e-5)
+    slot = eng.forward_backward(0, None, 0, batch, batch)
+    loss = eng._read_losses(slot, 1)[0]
+    eng.sync()
+    loss_ref, _ = ref.loss_and_grads(x, t)
+    assert abs(loss - loss_ref) <= 2e-6 * abs(loss_ref)
+    noisy = bn_bias_keys(spec.save())
+    worst = 0.0
+    for k, gr in ref.grads().items():
+        if k in noisy:
+            continue
+        got = eng.grad_view(k).cpu().numpy()
+        worst = max(worst, float(np.abs(got - gr.numpy()).max()) / float(gr.abs().max()))
+    assert worst <= (2e-4 if batch == 64 else 2e-3), worst   # small batches make BatchNorm ill-conditioned (DESIGN.md §2)
+    eng.profile_begin()
+    eng.forward_backward(0, None, 0, batch, batch)
+    labels = [name for (name, layer, us, nbytes) in eng.profile_end()]
+    assert labels.count("ct_convt_bwd") == 3 and "ig_convt_bwd_pair" not in labels, labels

@@ -3,6 +3,7 @@ thread 0 of the first 384 workgroups at the phase boundaries (CAE_HEAD_DBG=4 / 5
 
     python tools/last_phases.py [batch]                 # the fused last layer
     python tools/last_phases.py [batch] rows [layer]    # the row-streaming backward of decoder layer `layer` (default 4)
+    python tools/last_phases.py [batch] ctb [layer]     # the LDS-staged backward (kernels_ctbwd.h) of decoder layer 0..2 (CAE_HEAD_DBG=6)
 """
 import os
 import sys
@@ -11,15 +12,17 @@ import numpy as np
 import torch
 
 ROWS = len(sys.argv) > 2 and sys.argv[2] == "rows"
-os.environ["CAE_HEAD_DBG"] = "5" if ROWS else "4"
-if ROWS and len(sys.argv) > 3:
+CTB = len(sys.argv) > 2 and sys.argv[2] == "ctb"
+os.environ["CAE_HEAD_DBG"] = "6" if CTB else "5" if ROWS else "4"
+if (ROWS or CTB) and len(sys.argv) > 3:
     os.environ["CAE_DBG_LAYER"] = sys.argv[3]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from cae_tools_amd.engine import HipEngine                     # noqa: E402
 from cae_tools_amd.models.model_sizer import create_model_spec  # noqa: E402
 
-PHASES = (["consts + issue loads", "barrier (weights in LDS)", "first row", "remaining rows", "reductions + atomics"] if ROWS else
+PHASES = (["issue loads", "constants + small staging", "gradient maps to LDS", "MFMA tasks", "producer sums"] if CTB else
+          ["consts + issue loads", "barrier (weights in LDS)", "first row", "remaining rows", "reductions + atomics"] if ROWS else
           ["issue loads", "BatchNorm consts + weights", "first row", "remaining rows", "reductions + atomics"])
 
 
