@@ -556,8 +556,10 @@ void last_fused_launch(S2Last a, hipStream_t s) {
         const int wmax = a.W > a.QW - 1 ? a.W : a.QW - 1, hmax = a.H > a.QH - 1 ? a.H : a.QH - 1;
         a.strips = (wmax + kLastStripPx - 1) / kLastStripPx;
         // a wave walks a band of HB quad rows (+1 recomputed): taller bands recompute less, shorter ones give more waves
-        // (measured at the benchmark geometry: 2048 waves of 4+1 rows, two per SIMD, beat 1024 of 8+1: 20.4 against 21.8 us)
-        int hb = hb_env ? hb_env : ((long long)a.B * a.strips * ((hmax + 7) / 8) >= 2048 ? 8 : 4);
+        // (measured at the benchmark geometry: 2048 waves of 4+1 rows, two per SIMD, beat 1024 of 8+1: 20.4 against 21.8 us;
+        // and at batch 128 / 512, where 8+1 rows used to be chosen: 244.2 against 246.8 and 601.6 against 607.6 us per step -
+        // the 8-row variant's register arrays end up in scratch)
+        int hb = hb_env ? hb_env : 4;
         if (hb != 8) hb = 4;
         a.bands = (hmax + hb - 1) / hb;
         a.total = a.B * a.strips * a.bands;
