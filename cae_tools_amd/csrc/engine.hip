@@ -21,11 +21,15 @@
 #include "kernels_gemm.h"
 #include "kernels_igemm.h"
 #include "kernels_ctlds.h"
-#include "kernels_ctbwd.h"
 #include "kernels_head.h"
 #include "dp_comm.h"
+#include "kernels_ctbwd.h"   // argument struct only: the kernel lives in ctbwd.hip
 
 using namespace cae;
+
+namespace cae_internal {
+int ctbwd_launch(const void* args, size_t bytes, unsigned gx, unsigned gy, unsigned gz, size_t lds, hipStream_t s);   // ctbwd.hip
+}
 
 namespace {
 
@@ -1304,10 +1308,10 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                     }
                     ProfScope _p(e, "ct_convt_bwd", l,
                                  f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));
-                    head_lds_attr(k_ct_bwd_lds, lds);
                     static const int wg_target = env_int("CAE_CTBWD_WGS", 256);   // env: tuning only
                     const int parts = std::max(1, std::min(8, wg_target / (groups * (L.cin / 16))));
-                    hipLaunchKernelGGL(k_ct_bwd_lds, dim3((unsigned)groups, (unsigned)(L.cin / 16), (unsigned)parts), dim3(kCtbThreads), lds, s, c);
+                    if (cae_internal::ctbwd_launch(&c, sizeof c, (unsigned)groups, (unsigned)(L.cin / 16), (unsigned)parts, lds, s))
+                        return fail(CAE_ERR_ARG, "k_ct_bwd_lds: argument layout mismatch");
                     if (l > 0)
                         if (int rc = sync_bn_table(e, a, e->dec[l - 1].bn_index)) return rc;
                     continue;

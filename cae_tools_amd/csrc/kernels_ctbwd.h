@@ -58,6 +58,7 @@ inline size_t ct_bwd_lds_bytes(int Cin, int Cout, int imgs, int HW, int OHW, int
     return (floats + 8) * sizeof(float);
 }
 
+#ifdef CAE_CTBWD_KERNEL   // the kernel itself is compiled in its own translation unit (ctbwd.hip); engine.hip sees the structs only
 // grid (B / imgs rounded up, Cin / 16, parts), block kCtbThreads, dynamic LDS = ct_bwd_lds_bytes(...)
 __global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
     extern __shared__ double lds_d[];
@@ -336,5 +337,6 @@ __global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
     CTB_STAMP(5);
 #undef CTB_STAMP
 }
+#endif   // CAE_CTBWD_KERNEL
 
 }  // namespace cae
