@@ -61,6 +61,7 @@ inline size_t ct_bwd_lds_bytes(int Cin, int Cout, int imgs, int HW, int OHW, int
 #ifdef CAE_CTBWD_KERNEL   // the kernel itself is compiled in its own translation unit (ctbwd.hip); engine.hip sees the structs only
 // grid (B / imgs rounded up, Cin / 16, parts), block kCtbThreads, dynamic LDS = ct_bwd_lds_bytes(...)
 __global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
+    kernarg_warm<sizeof(CtBwd)>();
     extern __shared__ double lds_d[];
     float* lstat = reinterpret_cast<float*>(lds_d);                     // [16][2]
     float4* cout4 = reinterpret_cast<float4*>(lstat + 32);              // [Cout]

@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(512) k_ct_fwd_lds(CtFwd a) {
     static_assert(KH >= 2 && KH <= 4 && KW >= 2 && KW <= 4, "stride-2 kernels of 2..4 taps per axis");
 
 #define CT_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 384) a.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+    kernarg_warm<sizeof(CtFwd)>();
     extern __shared__ double lds_d[];
     CT_STAMP(0);
     double* lstat = lds_d;                                          // [16 channels][2]

@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(256) k_gemm16(GemmArgs g) {
 // two independent GEMMs in one launch (a Linear layer's weight gradient beside its input gradient):
 // workgroups [0, na) run `a`, the rest run `b`
 __global__ void __launch_bounds__(256) k_gemm16_pair(GemmArgs a, GemmArgs b, int na, int b_burst) {
+    kernarg_warm<2 * sizeof(GemmArgs) + 8>();
     extern __shared__ double lds_d[];
     if ((int)blockIdx.x < na) gemm16_body(a, blockIdx.x, lds_d);
     else if (b_burst) gemm16_burst_body(b, blockIdx.x - na, lds_d);

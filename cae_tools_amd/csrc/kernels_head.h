@@ -467,6 +467,7 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(HeadArgs a) {
     extern __shared__ double lds_d[];
     float* lds = reinterpret_cast<float*>(lds_d);
     const int tid = threadIdx.x;
+    kernarg_warm<sizeof(HeadArgs)>();
     const bool first = blockIdx.x == 0 && blockIdx.y == 0;
     // no kernel of the forward/backward pass reads adam_step, so bumping it here cannot race
     if (first && tid == 0 && a.bump_adam) const_cast<StepState*>(a.st)->adam_step += 1;
@@ -683,6 +684,7 @@ __device__ __forceinline__ void tail_wgrad(const float* g, int ldg, int nin, int
 
 // grid (ceil(B / 16), 4), block 1024
 __global__ void __launch_bounds__(kHeadThreads) k_tail_bwd(TailArgs a) {
+    kernarg_warm<sizeof(TailArgs)>();
     extern __shared__ double lds_d[];
     float* lds = reinterpret_cast<float*>(lds_d);
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;

@@ -572,6 +572,7 @@ __global__ void __launch_bounds__(256) k_ig_wgrad(IgWgrad a) {
 // grid = ig_pair_blocks(...): w_n8 = ceil(chunks / 8), d_n8 = ceil(ceil(d_gx / d_group) / 8).
 __global__ void __launch_bounds__(256) k_ig_bwd_pair(IgWgrad w, IgDgrad d, int w_tiles, int w_chunks, int w_n8, int d_gx,
                                                       int d_gy, int d_group) {
+    kernarg_warm<sizeof(IgWgrad) + sizeof(IgDgrad) + 24>();
     extern __shared__ double lds_d[];
     const int nw = 8 * w_tiles * w_n8;
     const int id = blockIdx.x, x = id & 7;

@@ -106,6 +106,7 @@ __device__ __forceinline__ void wave_sums_lds(const float (&v)[N], float* scr, f
 // VEC4: output rows are 16-byte aligned and there is one strip (OW % 4 == 0, strips == 1): 16-byte target loads
 template <int CIN, int COUT, int KH, int KW, int HB, bool VEC4, bool BN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_s2_last_fused(S2Last a) {
+    kernarg_warm<sizeof(S2Last)>();
     constexpr int NACC = CIN * COUT * KH * KW;
     constexpr int NRED = NACC + 2 * CIN;
     constexpr int NR = HB + 1;            // quad rows a wave computes: its band + the first row of the next one

@@ -41,6 +41,7 @@ struct S2Rows {
 // CT input channels per wave (CS = CIN / CT channel groups = waves sharing a band), IMGS images side by side in a wave
 template <int CIN, int CT, int COUT, int KH, int KW, int HB, int IMGS, int D>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_s2_bwd_rows(S2Rows a) {
+    kernarg_warm<sizeof(S2Rows)>();
     constexpr int CS = CIN / CT;             // waves that share a band (channel groups)
     constexpr int NB = 4 / CS;               // bands per workgroup
     constexpr int LW = 64 / IMGS;            // lanes (quad columns) per image
@@ -380,6 +381,7 @@ struct S2FwdRows {
 
 template <int CIN, int COUT, int HB, int IMGS>
 __global__ void __launch_bounds__(256) k_s2_fwd_rows(S2FwdRows a) {
+    kernarg_warm<sizeof(S2FwdRows)>();
     constexpr int KH = 3, KW = 3;
     constexpr int LW = 64 / IMGS;
     constexpr int NRED = 2 * COUT;
