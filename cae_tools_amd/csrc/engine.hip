@@ -25,6 +25,17 @@
 #include "dp_comm.h"
 #include "kernels_ctbwd.h"   // argument struct only: the kernel lives in ctbwd.hip
 
+// The benchmark geometry's template kernels, instantiated HERE so that their code sits next to the non-template kernels of
+// the same step (implicit instantiations are emitted at the end of the 3 MB text section, 2 MB away): see DESIGN.md §4.
+namespace cae {
+template __global__ void k_ct_fwd_lds<3, 3>(CtFwd);
+template __global__ void k_s2_fwd_rows<8, 4, 1, 2>(S2FwdRows);
+template __global__ void k_s2_fwd_rows<4, 2, 2, 1>(S2FwdRows);
+template __global__ void k_s2_last_fused<2, 1, 4, 4, 4, true, true>(S2Last);
+template __global__ void k_s2_bwd_rows<4, 4, 2, 3, 3, 2, 1, 3>(S2Rows);
+template __global__ void k_s2_bwd_rows<8, 2, 4, 3, 3, 4, 2, 1>(S2Rows);
+}  // namespace cae
+
 using namespace cae;
 
 namespace cae_internal {
