@@ -128,6 +128,9 @@ struct cae_engine {
     bool graph_mode = true;
     bool use_s2 = true;  // specialised stride-2 kernels (cae_set_kernel_mode)
     int ctbwd_mask = 0;  // bit l: decoder layer l's backward runs the LDS-staged kernel (kernels_ctbwd.h) where eligible
+    int64_t off_xbatch = 0;     // the current batch's inputs, contiguous (written by k_head_fwd, read by k_adam's fused conv-0 weight gradient)
+    bool x_published = false;   // this step's k_head_fwd wrote them
+    AdamConv0 c0_pending{};     // filled by launch_backward when the conv-0 weight gradient is left to k_adam
     // profiling (cae_profile_begin/end): every launch bracketed by an event pair, plain launches
     bool profiling = false;
     struct ProfRec { const char* name; int layer; double bytes; hipEvent_t e0, e1; };
@@ -319,6 +322,7 @@ struct StepArgs {
     int cursor_inc = -1;   // samples the cursor moves per step (-1: batch; the global batch under data parallelism)
     // module-level forward (cae_encode / cae_decode): 0 = the whole network, 1 = encoder only (x_direct -> z_out),
     // 2 = decoder only (z_in -> yhat); eval mode, per-layer launches
+    bool adam_follows = false;   // OP_TRAIN on one device: k_adam is the next launch (it may take the first encoder layer's weight gradient)
     int part = 0;
     const float* z_in = nullptr;
     float* z_out = nullptr;
@@ -916,7 +920,7 @@ int dp_finish_step(cae_engine* e, const StepArgs& a) {
     ProfScope _p(e, "adam", 0, 28.0 * e->n_param);
     hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
                        (const float*)e->grads, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(), none, 0,
-                       std::log(e->hp.beta1), std::log(e->hp.beta2));
+                       std::log(e->hp.beta1), std::log(e->hp.beta2), AdamConv0{});
     return CAE_OK;
 }
 
@@ -941,10 +945,24 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
         for (auto& L : e->enc) bytes += f4((double)B * (L.in_elems() + L.out_elems()));
         for (int i = 0; i < 4; i++) bytes += f4((double)B * (e->fc[i].nin + e->fc[i].nout) + (double)e->fc[i].nin * e->fc[i].nout);
         head_lds_attr(k_head_fwd, head_lds);
+        e->x_published = false;
+        if (a.train) {
+            // EVERY training forward clears the first encoder layer's BatchNorm table before anything adds to it: a fused
+            // optimiser launch (AdamConv0) reads that table and therefore leaves it dirty, and which kind of step ran last
+            // is not something a captured graph can know (the per-layer path below does the same with a fill launch)
+            head.clear0 = e->bn_stats(e->enc[0].bn_index);
+            head.clear0_n = kStatShards * e->enc[0].cout * 4;
+            if (a.adam_follows) {
+                head.xbatch = e->fptr(e->off_xbatch);
+                e->x_published = true;
+            }
+        }
         ProfScope _p(e, a.train ? "head_fwd" : "head_eval", 0, bytes);
         hipLaunchKernelGGL(k_head_fwd, dim3((B + 15) / 16, (T + head.tiles_per_wg - 1) / head.tiles_per_wg), dim3(kHeadThreads),
                            head_lds, s, head);
     }
+    if (!fused_head && a.train && a.part == 0)   // (see the fused launch above: every training forward clears this table first)
+        HIP_TRY(hipMemsetAsync(e->bn_stats(e->enc[0].bn_index), 0, (size_t)kStatShards * e->enc[0].cout * 4 * sizeof(double), s));
     // ---- encoder convs (encoder.py:40-46)
     for (size_t l = 0; !fused_head && a.part != 2 && l < e->enc.size(); l++) {
         const ConvLayer& L = e->enc[l];
@@ -1586,6 +1604,23 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                                wa, ua, (int)nw, nwy, ux, st);
             continue;
         }
+        memset(&e->c0_pending, 0, sizeof e->c0_pending);
+        if (l == 0 && a.adam_follows && e->x_published && e->use_s2 && !a.syncing() && a.world == 1 && L.cout <= 64 &&
+            (int64_t)L.cin * L.cout * L.kh * L.kw <= 4096 && (int64_t)B * L.hout * L.wout < kDivSmallMaxN &&
+            L.hout * L.wout < kDivSmallMaxD && e->bn_stat_off[L.bn_index] == e->off_zero_begin) {
+            // the last launch of backward folds into the optimiser launch (kernels_generic.h AdamConv0)
+            AdamConv0& c0 = e->c0_pending;
+            c0.on = 1;
+            c0.nw = L.cin * L.cout * L.kh * L.kw;
+            c0.C = L.cout;
+            c0.w_off = L.w_off; c0.gamma_off = L.gamma_off; c0.beta_off = L.beta_off;
+            c0.g = g; c0.small = gy; c0.bns = bng;
+            c0.xb = e->fptr(e->off_xbatch);
+            c0.bns.gamma = c0.xb + (int64_t)B * L.in_elems();   // k_head_fwd's copy: this launch rewrites the parameter itself
+            c0.stats = e->bn_stats(L.bn_index);
+            c0.scale = 1.0;
+            continue;
+        }
         {
             const int64_t nw = (int64_t)L.cin * L.cout * L.kh * L.kw;
             const int64_t pos = (int64_t)B * L.hout * L.wout;
@@ -1656,15 +1691,31 @@ int launch_one(cae_engine* e, int op, const StepArgs& a) {
     } else if (op == OP_TRAIN || op == OP_FWDBWD) {
         // the accumulators were zeroed by the previous step's last kernel (k_adam / k_acc_to_f32) or by
         // the caller's zero-filled workspace on the very first step
-        int rc = launch_forward(e, a);
+        static const int fuse_c0 = env_int("CAE_ADAM_CONV0", 1);   // env: A/B measurements only
+        StepArgs af = a;
+        af.adam_follows = op == OP_TRAIN && fuse_c0 != 0;
+        memset(&e->c0_pending, 0, sizeof e->c0_pending);
+        int rc = launch_forward(e, af);
         if (rc) return rc;
-        rc = launch_backward(e, a);
+        rc = launch_backward(e, af);
         if (rc) return rc;
         if (op == OP_TRAIN) {
             ProfScope _p(e, "adam", 0, 32.0 * e->n_param);
-            hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
+            AdamConv0 c0 = e->c0_pending;
+            StepTail tl = step_tail_of(e, a.inc(), 1);
+            int nreg = grid1(e->n_param), grid = nreg;
+            if (c0.on) {
+                // that layer's BatchNorm table (the first of the swept range) is read by this launch: the next step's
+                // k_head_fwd clears it
+                const long long skip = (long long)kStatShards * c0.C * 4;
+                tl.zero_extra += skip;
+                tl.zero_extra_n -= skip;
+                c0.n_regular = nreg;
+                grid = nreg + c0.nw;
+            }
+            hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, s, (long long)e->n_param, e->params,
                                (const float*)nullptr, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(),
-                               step_tail_of(e, a.inc(), 1), 0, std::log(e->hp.beta1), std::log(e->hp.beta2));
+                               tl, 0, std::log(e->hp.beta1), std::log(e->hp.beta2), c0);
         } else {
             hipLaunchKernelGGL(k_acc_to_f32, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->grads,
                                e->shard_segs(), step_tail_of(e, a.inc(), 1));
@@ -1679,7 +1730,7 @@ int launch_one(cae_engine* e, int op, const StepArgs& a) {
         // forward_backward already counted this optimiser step (its first kernel bumps adam_step)
         hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, s, (long long)e->n_param, e->params,
                            (const float*)e->grads, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(),
-                           none, 0, std::log(e->hp.beta1), std::log(e->hp.beta2));
+                           none, 0, std::log(e->hp.beta1), std::log(e->hp.beta2), AdamConv0{});
     }
     HIP_TRY(hipGetLastError());
     return CAE_OK;
@@ -1905,6 +1956,7 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
         L.grad_off = carve(top, mb * L.out_elems() * 4);
     }
     e->off_glast = carve(top, mb * e->dec.back().out_elems() * 4);
+    e->off_xbatch = carve(top, (mb * e->enc[0].in_elems() + e->enc[0].cout) * 4);   // + the layer's gamma before the update
     e->ws_need = align_up(top, 256);
     for (auto& L : e->enc)
         if (L.cin > e->max_channels) e->max_channels = L.cin;

@@ -843,6 +843,90 @@ __device__ __forceinline__ void step_tail(const StepTail& tl, long long gid, lon
 // over the flat arena.  Gradient source: fp64 accumulators (fused path; consumed and cleared) or
 // the fp32 arena (data-parallel path, after the all-reduce).  st->adam_step is the number of the
 // step being taken (bumped by the first kernel of the step / by cae_adam_step's own bump flag).
+// The first encoder layer's weight gradient, folded into the optimiser launch (k_adam): it is the last kernel of backward, a
+// reduction of B*Hs*Ws products per weight that nothing but the optimiser waits for - as its own launch 5.6 us, 3 % of the
+// step.  One extra workgroup per weight: it reduces the whole batch itself (no cross-workgroup sum, so no ordering between
+// the reduction and the update), then updates that one parameter.  The inputs come from the contiguous copy of the batch
+// that k_head_fwd leaves behind (the cursor has moved on by now: this kernel moves it).  The BatchNorm parameter gradients
+// of that layer, which the weight-gradient launch used to turn from sums into accumulator entries, are taken from the sums
+// directly by the threads that own gamma and beta; the layer's sum table is left for the next step's first kernel to clear.
+struct AdamConv0 {
+    int on, nw, C, n_regular;   // n_regular: workgroups of the element-wise update (then one per weight)
+    long long w_off, gamma_off, beta_off;
+    ConvGeom g;
+    Src small;                  // p = masked gradient of the layer's output, q = its raw output (BN_BWD)
+    BnDesc bns;
+    const float* xb;            // (B, Cl, Hl, Wl) the batch's inputs, contiguous
+    const double* stats;        // the layer's BatchNorm table [shards][C][4]
+    double scale;               // 1 / world (1 here: the fused form is single-device only)
+};
+constexpr int kAdamConv0Pos = 16;   // positions per thread requested in one burst
+
+__device__ __forceinline__ void adam_conv0_body(const AdamConv0& c0, float* __restrict__ p, float* __restrict__ m,
+                                                float* __restrict__ v, const Hyper& h, const StepState* __restrict__ st,
+                                                int t_add, double ln_b1, double ln_b2, float* corr, double* red, float4* cs4) {
+    const ConvGeom& g = c0.g;
+    const int tid = threadIdx.x;
+    int widx = blockIdx.x - c0.n_regular;
+    const int kx = widx % g.kw;
+    widx /= g.kw;
+    const int ky = widx % g.kh;
+    widx /= g.kh;
+    const int cl = widx % g.Cl;
+    const int cs = widx / g.Cl;
+    const long long pi = c0.w_off + (blockIdx.x - c0.n_regular);
+    int t = 0;
+    if (tid < 2) t = st->adam_step + t_add;
+    float w = 0.f, mi = 0.f, vi = 0.f;
+    if (tid == 0) {
+        w = p[pi];
+        mi = m[pi];
+        vi = v[pi];
+    }
+    const int hw = g.Hs * g.Ws, n = g.B * hw;
+    const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)g.Ws;
+    auto fetch = [&](int pp, float& sp, float& sq, float& lp) {
+        const int b = div_small(pp, inv_hw), r = pp - b * hw;
+        const int y = div_small(r, inv_w), x = r - y * g.Ws;
+        const size_t so = ((size_t)(b * g.Cs + cs) * g.Hs + y) * g.Ws + x;
+        sp = c0.small.p[so];
+        sq = c0.small.q[so];
+        lp = c0.xb[((size_t)(b * g.Cl + cl) * g.Hl + (y * g.s + ky)) * g.Wl + x * g.s + kx];
+    };
+    float sp[kAdamConv0Pos], sq[kAdamConv0Pos], lp[kAdamConv0Pos];
+#pragma unroll
+    for (int u = 0; u < kAdamConv0Pos; u++) fetch(min(tid + u * 256, n - 1), sp[u], sq[u], lp[u]);
+#pragma unroll
+    for (int u = 0; u < kAdamConv0Pos; u++) asm volatile("" : "+v"(sp[u]), "+v"(sq[u]), "+v"(lp[u]));
+    bn_consts(c0.bns, cs4, false);
+    if (tid < 2) {
+        const double bc = -expm1((double)t * (tid ? ln_b2 : ln_b1));
+        corr[tid] = tid ? (float)sqrt(bc) : (float)(h.lr / bc);
+    }
+    __syncthreads();
+    const float4 ks = cs4[cs];
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < kAdamConv0Pos; u++)
+        if (tid + u * 256 < n) sum = fmaf(bn_apply(BN_BWD, ks, sp[u], sq[u]), lp[u], sum);
+    for (int pp = tid + kAdamConv0Pos * 256; pp < n; pp += 256) {
+        float a, b, c;
+        fetch(pp, a, b, c);
+        sum = fmaf(bn_apply(BN_BWD, ks, a, b), c, sum);
+    }
+    const double tot = block_sum((double)sum, red);
+    if (tid == 0) {
+        float gr = (float)(tot * c0.scale);
+        if (h.wd != 0.0) gr = fmaf((float)h.wd, w, gr);
+        mi = mi + (gr - mi) * (float)(1.0 - h.beta1);
+        vi = vi * (float)h.beta2 + ((float)(1.0 - h.beta2) * gr) * gr;
+        const float denom = sqrtf(vi) / corr[1] + (float)h.eps;
+        p[pi] = w - corr[0] * (mi / denom);
+        m[pi] = mi;
+        v[pi] = vi;
+    }
+}
+
 // `ln_b1`, `ln_b2`: natural logarithms of the betas (host).
 // Order matters, this being the one kernel every step ends with: every thread requests its parameter, moments and gradient
 // first; the bias corrections 1 - beta^t = -expm1(t ln beta) are worked out meanwhile by two lanes, one each (the two fp64
@@ -851,15 +935,21 @@ __device__ __forceinline__ void step_tail(const StepTail& tl, long long gid, lon
 __global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p, const float* __restrict__ g32,
                                                float* __restrict__ m, float* __restrict__ v, Hyper h,
                                                const StepState* __restrict__ st, ShardSegs ss, StepTail tl, int t_add,
-                                               double ln_b1, double ln_b2) {
-    kernarg_warm<sizeof(Hyper) + sizeof(ShardSegs) + sizeof(StepTail) + 72>();
+                                               double ln_b1, double ln_b2, AdamConv0 c0) {
+    kernarg_warm<sizeof(Hyper) + sizeof(ShardSegs) + sizeof(StepTail) + 72 + sizeof(AdamConv0)>();
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     __shared__ float corr[2];
+    if (c0.on && (int)blockIdx.x >= c0.n_regular) {   // uniform per workgroup
+        __shared__ double red0[8];
+        __shared__ float4 cs40[64];
+        adam_conv0_body(c0, p, m, v, h, st, t_add, ln_b1, ln_b2, corr, red0, cs40);
+        return;
+    }
     // The step tail (step_tail's work) first.  No kernel of this step reads the BatchNorm sum tables any more, and nobody in
     // this kernel reads the cursor: cleared / moved up here, the stores complete in the shadow of the loads below.  Behind
     // the parameter update they cost a wait of their own: registers are reused there, and the compiler then waits for the
     // stores ahead of them (the memory counter retires in order).
-    for (long long j = i; j < tl.zero_extra_n; j += (long long)gridDim.x * 256) tl.zero_extra[j] = 0.0;
+    for (long long j = i; j < tl.zero_extra_n; j += (long long)(c0.on ? c0.n_regular : (int)gridDim.x) * 256) tl.zero_extra[j] = 0.0;
     int t = 0;
     if (threadIdx.x < 2) t = st->adam_step + t_add;
     const bool moves_cursor = i == 0 && tl.st != nullptr;
@@ -869,13 +959,14 @@ __global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p
         cursor = tl.st->batch_start;
         slot = tl.st->loss_slot;
     }
-    const bool mine = i < n;
+    const bool mine = i < n && !(c0.on && i >= c0.w_off && i < c0.w_off + c0.nw);   // those weights: adam_conv0_body
     float g = 0.f, w = 0.f, mi = 0.f, vi = 0.f;
     // the fp64 gradient: its accumulator plus, for a parameter that is accumulated in shards, the eight shard copies.
     // Requested here, added up behind the barrier, cleared by the kernel's last stores (consume_grad's clearing stores sit
     // between its loads and their use, and where its paths meet the compiler waits for all but one of them to complete)
-    double gacc = 0.0, sv[kStatShards];
+    double gacc = 0.0, sv[kStatShards], bv[kStatShards];
     double* shp = nullptr;
+    const double* bnp = nullptr;
     if (mine) {
         w = p[i];
         mi = m[i];
@@ -891,6 +982,15 @@ __global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p
             if (shp) {
 #pragma unroll
                 for (int sh = 0; sh < kStatShards; sh++) sv[sh] = shp[(size_t)sh * ss.n];
+            }
+            if (c0.on) {   // gamma / beta of the fused layer: straight from its BatchNorm-backward sums (slots 3 / 2)
+                const long long dg = i - c0.gamma_off, db = i - c0.beta_off;
+                if (dg >= 0 && dg < c0.C) bnp = c0.stats + dg * 4 + 3;
+                if (db >= 0 && db < c0.C) bnp = c0.stats + db * 4 + 2;
+                if (bnp) {
+#pragma unroll
+                    for (int sh = 0; sh < kStatShards; sh++) bv[sh] = bnp[(size_t)sh * c0.C * 4];
+                }
             }
         }
     }
@@ -911,6 +1011,12 @@ __global__ void __launch_bounds__(256) k_adam(long long n, float* __restrict__ p
             if (shp) {
 #pragma unroll
                 for (int sh = 0; sh < kStatShards; sh++) gacc += sv[sh];
+            }
+            if (bnp) {
+                double t2 = 0.0;
+#pragma unroll
+                for (int sh = 0; sh < kStatShards; sh++) t2 += bv[sh];
+                gacc += t2 * c0.scale;
             }
             g = (float)gacc;
         }

@@ -90,6 +90,9 @@ struct HeadArgs {
     int piece_m[kHeadW4];   // matrix that holds ALL of piece j (float4s [j, j + 1) * kHeadThreads), or -1 when it straddles two
     int n_seg;          // head: small read-only vectors copied to LDS in one burst (<= 1024 floats each)
     HeadSeg seg[kHeadMaxSeg];
+    float* xbatch;      // head, training: the first workgroup leaves the staged input batch here, contiguous (k_adam's fused conv-0 weight gradient)
+    double* clear0;     // ... and clears these clear0_n doubles (the first encoder layer's BatchNorm sum table, which k_adam then leaves alone)
+    int clear0_n;
     long long* dbg;     // diagnostics (tools/head_phases.py): per workgroup 16 wall-clock stamps, or nullptr
 };
 
@@ -540,6 +543,17 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(HeadArgs a) {
     for (int i = tid; i < 32 * a.ld_h + 32; i += kHeadThreads) lds[a.o_h[0] + i] = 0.f;   // both panels (adjacent), padding and guard included
     head_stamp(a, 1);
     head_stage_inputs(a, lds, bs);
+    if (first) {   // uniform per workgroup
+        if (a.xbatch) {
+            const HeadConv& L0 = a.enc[0];
+            const int nx = a.B * L0.cin * L0.hin * L0.win;
+            for (int i = tid; i < nx; i += kHeadThreads) a.xbatch[i] = lds[a.o_x + i];
+            // ... and the layer's BatchNorm gamma as it is NOW, behind the batch: the optimiser launch that takes this layer's
+            // weight gradient rewrites gamma while its other workgroups still need the old value (BN-backward constants)
+            if (tid < L0.cout) a.xbatch[nx + tid] = lds[L0.o_gamma + tid];
+        }
+        for (int i = tid; i < a.clear0_n; i += kHeadThreads) a.clear0[i] = 0.0;
+    }
     head_stamp(a, 2);
     head_encoder(a, lds, first);
     f32x4 wlate[kHeadW4 - kHeadEarly];

@@ -386,3 +386,28 @@ def test_multi_step_graph_equals_single_steps():
     # 67 Adam steps apart the two runs differ only by the arrival order of the fp64 atomics
     np.testing.assert_allclose(a[2], b[2], rtol=1e-5, atol=5e-6)
     np.testing.assert_allclose(a[3], b[3], rtol=1e-5, atol=5e-6)
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_fused_optimiser_launch_sees_the_same_gradients(name):
+    """The training step's last launch (k_adam) also computes the first encoder layer's weight gradient and that layer's
+    BatchNorm parameter gradients (kernels_generic.h AdamConv0); forward_backward() keeps them as separate launches.  After
+    ONE step from zero moments exp_avg = (1 - beta1) (g + wd w): every parameter's g recovered from the fused step must be
+    the gradient the separate launches produce.  (This is the test that catches a workgroup of the fused launch reading a
+    parameter another workgroup of the same launch has already updated: 1e-3 relative on gamma-dependent entries.)"""
+    case = GoldenCase(name)
+    n = case.x.shape[0] + case.x2.shape[0]
+    a = _engine(case, max_batch=max(8, n))
+    _dataset(a, case)
+    a.forward_backward(0, None, 0, n, n)
+    a.sync()
+    g_sep = a.grads.cpu().numpy().astype(np.float64)
+    w0 = a.params.cpu().numpy().astype(np.float64)
+    b = _engine(case, max_batch=max(8, n))
+    _dataset(b, case)
+    b.train_step(0, None, 0, n)
+    b.sync()
+    g_fused = b.exp_avg.cpu().numpy().astype(np.float64) / 0.1 - case.meta["weight_decay"] * w0
+    # exp_avg is fp32: its rounding (6e-8 relative to g + wd w) is what the comparison can resolve
+    scale = np.abs(g_sep) + case.meta["weight_decay"] * np.abs(w0)
+    assert float(np.max(np.abs(g_fused - g_sep) - 1e-6 * scale)) <= 1e-7 * float(np.abs(g_sep).max())
