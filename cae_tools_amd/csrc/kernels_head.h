@@ -543,7 +543,8 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(HeadArgs a) {
     for (int i = tid; i < 32 * a.ld_h + 32; i += kHeadThreads) lds[a.o_h[0] + i] = 0.f;   // both panels (adjacent), padding and guard included
     head_stamp(a, 1);
     head_stage_inputs(a, lds, bs);
-    if (first) {   // uniform per workgroup
+    // (the LAST workgroup: the first one already publishes the encoder's outputs and statistics)
+    if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) {   // uniform per workgroup
         if (a.xbatch) {
             const HeadConv& L0 = a.enc[0];
             const int nx = a.B * L0.cin * L0.hin * L0.win;
