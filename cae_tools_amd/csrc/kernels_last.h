@@ -149,6 +149,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     long long bs_v = 0;
     const bool indirect = a.perm != nullptr || a.use_cursor != 0;
     if (indirect) bs_v = (&a.st->batch_start)[lane_zero];
+    // (the loss slot rides along: read where the loss atomic is issued it is one more trip to memory at the very end of the
+    // workgroup's last lane)
+    const int loss_slot_v = (&a.st->loss_slot)[lane_zero];
     // BatchNorm sums of the producer: lane (8 c + shard) reads that shard's {sum y, sum y^2} of channel c (one 16-byte load)
     double sa = 0.0, sb = 0.0;
     float gam[CIN], bet[CIN], rmn[CIN], rvr[CIN];
@@ -528,7 +531,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
             double s = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; w++) s += redd[(w * COUT + co) * 2 + which];
-            if (which == 0) atomicAdd(&a.losses[(size_t)a.st->loss_slot * kStatShards + shard], s);
+            if (which == 0) atomicAdd(&a.losses[(size_t)loss_slot_v * kStatShards + shard], s);
             else atomicAdd(&a.bias_acc[(size_t)shard * a.acc_stride + co], s);
         }
     }
