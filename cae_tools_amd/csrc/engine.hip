@@ -128,6 +128,7 @@ struct cae_engine {
     bool graph_mode = true;
     bool use_s2 = true;  // specialised stride-2 kernels (cae_set_kernel_mode)
     int ctbwd_mask = 0;  // bit l: decoder layer l's backward runs the LDS-staged kernel (kernels_ctbwd.h) where eligible
+    int ctbwd_auto = 0;  // ... the mask chosen at creation (CAE_CTBWD, or the rule in cae_create): its layers have sharded accumulators
     int64_t off_xbatch = 0;     // the current batch's inputs, contiguous (written by k_head_fwd, read by k_adam's fused conv-0 weight gradient)
     bool x_published = false;   // this step's k_head_fwd wrote them
     AdamConv0 c0_pending{};     // filled by launch_backward when the conv-0 weight gradient is left to k_adam
@@ -1899,10 +1900,16 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
             // (... and the layers of the LDS-staged backward kernel, kernels_ctbwd.h: its workgroups all reach their weight-
             // gradient atomics at the same moment, one per image group and address; unsharded they queue up behind the
             // kernel's end - measured 8 us of a 16 us launch at the benchmark's third layer)
-            static const int ctb_env = env_int("CAE_CTBWD", 0);   // env: bit l = decoder layer l on the LDS-staged backward kernel
-            if (l == 0) e->ctbwd_mask = ctb_env;
-            const bool ctb = l < 31 && ((ctb_env >> l) & 1) && L.transposed && L.stride == 2 && L.kh == 3 && L.kw == 3 &&
-                             L.cin % 16 == 0 && L.cout % 4 == 0;
+            // Which layers take it by default: one block of 16 input channels (no staging repeated per block) and few enough
+            // weights that the optimiser's eight shard reads per weight stay cheap - at the benchmark geometry the 16 -> 8
+            // layer: 169.6 against 171.5 us per step; the 32 -> 16 and 64 -> 32 layers lose (172.9 / 175.7 on their own).
+            static const int ctb_env = env_int("CAE_CTBWD", -1);   // env: bit l = decoder layer l on the LDS-staged backward kernel
+            const bool ctb_shape = l < 31 && L.transposed && L.stride == 2 && L.kh == 3 && L.kw == 3 && L.cin % 16 == 0 &&
+                                   L.cout % 4 == 0;
+            const bool ctb = ctb_shape && (ctb_env >= 0 ? ((ctb_env >> l) & 1) != 0 : (L.cin == 16 && L.cin * L.cout * 9 <= 2048));
+            if (l == 0) e->ctbwd_auto = 0;
+            if (ctb) e->ctbwd_auto |= 1 << l;
+            e->ctbwd_mask = e->ctbwd_auto;
             if ((!s2_shape_ok(L) && !ctb) || e->segs.nseg + 2 > 12) continue;
             const int nw = L.cin * L.cout * L.kh * L.kw;
             L.sh_w = n;
@@ -2021,8 +2028,7 @@ int cae_set_graph_mode(cae_engine* e, int enabled) {
 
 int cae_set_kernel_mode(cae_engine* e, int specialised) {
     if (!e) return fail(CAE_ERR_ARG, "null engine");
-    static const int ctb_env = env_int("CAE_CTBWD", 0);   // a mask given by the environment at creation stays as it is
-    const int ctb = ctb_env ? ctb_env : ((specialised & 2) ? 0x7fffffff : 0);
+    const int ctb = (specialised & 2) ? 0x7fffffff : e->ctbwd_auto;   // bit 1: every eligible layer (unsharded where not chosen at creation)
     if (e->use_s2 != ((specialised & 1) != 0) || ctb != e->ctbwd_mask) e->drop_graphs();
     e->use_s2 = (specialised & 1) != 0;
     e->ctbwd_mask = ctb;

@@ -96,9 +96,9 @@ int cae_set_stream(cae_engine* e, void* hip_stream);
 int cae_set_graph_mode(cae_engine* e, int enabled);
 
 /* 1 (default): use the specialised kernels where a layer is eligible; 0: shape-generic kernels
- * everywhere (kept as an on-device cross-check of the specialised ones).  Bit 1 (value 3): the backward pass of the
- * channel-rich 3x3 stride-2 decoder layers runs the LDS-staged kernel (kernels_ctbwd.h) instead of the gather pair -
- * an alternative kept for comparison, not faster at the benchmark geometry. */
+ * everywhere (kept as an on-device cross-check of the specialised ones).  Bit 1 (value 3): the backward pass of EVERY
+ * eligible channel-rich 3x3 stride-2 decoder layer runs the LDS-staged kernel (kernels_ctbwd.h) instead of the gather
+ * pair; with 1 only the layers it is faster on do (one block of 16 input channels: DESIGN.md section 4). */
 int cae_set_kernel_mode(cae_engine* e, int specialised);
 
 /* torch.optim.Adam(lr, betas, eps, weight_decay) with L2 decay added to the gradient
