@@ -2028,7 +2028,8 @@ int cae_set_graph_mode(cae_engine* e, int enabled) {
 
 int cae_set_kernel_mode(cae_engine* e, int specialised) {
     if (!e) return fail(CAE_ERR_ARG, "null engine");
-    const int ctb = (specialised & 2) ? 0x7fffffff : e->ctbwd_auto;   // bit 1: every eligible layer (unsharded where not chosen at creation)
+    static const int force_env = env_int("CAE_CTBWD_FORCE", -1);   // env: A/B measurements only - run-time mask (unsharded where not chosen at creation)
+    const int ctb = (specialised & 2) ? 0x7fffffff : (force_env >= 0 ? force_env : e->ctbwd_auto);   // bit 1: every eligible layer
     if (e->use_s2 != ((specialised & 1) != 0) || ctb != e->ctbwd_mask) e->drop_graphs();
     e->use_s2 = (specialised & 1) != 0;
     e->ctbwd_mask = ctb;
