@@ -23,7 +23,15 @@ int ctbwd_launch(const void* args, size_t bytes, unsigned gx, unsigned gy, unsig
     ctbtu::cae::CtBwd c;
     if (bytes != sizeof c) return -1;
     memcpy(&c, args, sizeof c);
-    static size_t granted = 64 * 1024;
+    static size_t granted = 64 * 1024, granted_band = 64 * 1024;
+    if (c.bands > 1) {   // one band of one image per workgroup
+        if (lds > granted_band) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctbtu::cae::k_ct_bwd_band), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            granted_band = lds;
+        }
+        hipLaunchKernelGGL(ctbtu::cae::k_ct_bwd_band, dim3(gx, gy, gz), dim3(ctbtu::cae::kCtbThreads), lds, s, c);
+        return 0;
+    }
     if (lds > granted) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctbtu::cae::k_ct_bwd_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         granted = lds;

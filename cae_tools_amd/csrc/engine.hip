@@ -1339,8 +1339,23 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                     ProfScope _p(e, "ct_convt_bwd", l,
                                  f4((double)B * (L.out_elems() * (last ? 1.0 : 2.0) + L.in_elems() * (l == 0 ? 1.0 : 2.0))));
                     static const int wg_target = env_int("CAE_CTBWD_WGS", 256);   // env: tuning only
-                    const int parts = std::max(1, std::min(8, wg_target / (groups * (L.cin / 16))));
-                    if (cae_internal::ctbwd_launch(&c, sizeof c, (unsigned)groups, (unsigned)(L.cin / 16), (unsigned)parts, lds, s))
+                    static const int band_env = env_int("CAE_CTBWD_BANDS", 1);   // env: A/B measurements only
+                    int parts = std::max(1, std::min(8, wg_target / (groups * (L.cin / 16))));
+                    size_t lds_launch = lds;
+                    if (band_env && imgs == 1 && parts > 1) {
+                        // one image per workgroup and workgroups to spare: bands of input rows instead of workgroups that
+                        // stage the same image (where the band's pieces fit the band kernel's staging registers)
+                        const int hb = (L.hin + parts - 1) / parts, bands = (L.hin + hb - 1) / hb;
+                        const int gstr = (2 * hb + 1) * L.wout, astr = hb * L.win;
+                        if (bands > 1 && L.cout * gstr <= 8 * kCtbThreads && 16 * astr <= 2 * kCtbThreads) {
+                            c.bands = bands;
+                            c.hb = hb;
+                            parts = bands;
+                            lds_launch = (32 + 4 * (size_t)(L.cin + L.cout) + (size_t)L.cout * gstr + 4 + 16 * (size_t)astr + 4 +
+                                          16 * (size_t)wstr + 3 * (size_t)astr + (size_t)kCtbWaves * 16 * 17 + 8) * sizeof(float);
+                        }
+                    }
+                    if (cae_internal::ctbwd_launch(&c, sizeof c, (unsigned)groups, (unsigned)(L.cin / 16), (unsigned)parts, lds_launch, s))
                         return fail(CAE_ERR_ARG, "k_ct_bwd_lds: argument layout mismatch");
                     if (l > 0)
                         if (int rc = sync_bn_table(e, a, e->dec[l - 1].bn_index)) return rc;

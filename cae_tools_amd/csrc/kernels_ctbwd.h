@@ -25,6 +25,7 @@ namespace cae {
 struct CtBwd {
     int B, Cin, H, W, Cout, OH, OW;
     int imgs;              // images per workgroup
+    int bands, hb;         // bands > 1 (imgs == 1 only): gridDim.z workgroups split the image into bands of hb input rows
     int wstr;              // LDS row stride of the weight slice (odd)
     const float* g;        // (B,Cout,OH,OW) masked gradient
     const float* yout;     // raw forward output of this layer (BN_BWD) or nullptr
@@ -53,56 +54,94 @@ inline size_t ct_bwd_lds_bytes(int Cin, int Cout, int imgs, int HW, int OHW, int
     floats += (size_t)imgs * Cout * OHW;                  // gradient maps (a multiple of 4 floats: Cout % 4 == 0)
     floats += (size_t)imgs * 16 * HW;                     // producer outputs of the channel block
     floats += 16 * (size_t)wstr;                          // weight rows
-    floats += 2 * (size_t)imgs * HW;                      // position tables
+    floats += 3 * (size_t)imgs * HW;                      // position tables
     floats += (size_t)kCtbWaves * 16 * 17;                // per-wave transpose tile of the input-gradient epilogue
     return (floats + 8) * sizeof(float);
 }
 
 #ifdef CAE_CTBWD_KERNEL   // the kernel itself is compiled in its own translation unit (ctbwd.hip); engine.hip sees the structs only
-// grid (B / imgs rounded up, Cin / 16, parts), block kCtbThreads, dynamic LDS = ct_bwd_lds_bytes(...)
-__global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
-    kernarg_warm<sizeof(CtBwd)>();
+// grid (B / imgs rounded up, Cin / 16, parts or bands), block kCtbThreads, dynamic LDS = ct_bwd_lds_bytes(...)
+// BAND: the workgroup owns input rows [y0, y1) of ONE image: it stages only the gradient rows 2 y0 .. 2 y1 and its own
+// positions' producer outputs (4-byte loads: the pieces are not 16-byte aligned) and runs all of the band's tasks; otherwise
+// it stages whole images and gridDim.z workgroups split the task list.
+template <bool BAND>
+__device__ __forceinline__ void ct_bwd_body(const CtBwd& a) {
     extern __shared__ double lds_d[];
     float* lstat = reinterpret_cast<float*>(lds_d);                     // [16][2]
     float4* cout4 = reinterpret_cast<float4*>(lstat + 32);              // [Cout]
     float4* cin4 = cout4 + a.Cout;                                      // [Cin]
     const int HW = a.H * a.W, OHW = a.OH * a.OW, KK = 9, N = a.Cout * KK;
-    float* gimg = reinterpret_cast<float*>(cin4 + a.Cin);              // [imgs][Cout][OHW]   (16-byte aligned)
-    float* araw = gimg + a.imgs * a.Cout * OHW;                        // [imgs][16][HW]      (16-byte aligned)
-    float* wl = araw + a.imgs * 16 * HW;                               // [16][wstr]
-    int* pos_g = reinterpret_cast<int*>(wl + 16 * a.wstr);             // [imgs*HW] offset of (img, 2y, 2x) inside gimg
-    int* pos_a = pos_g + a.imgs * HW;                                  // [imgs*HW] offset of (img, pos) inside araw (channel 0)
-    float* tiles = reinterpret_cast<float*>(pos_a + a.imgs * HW);      // [waves][16 positions][17]
-#define CTB_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x < 384) a.dbg[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
-    CTB_STAMP(0);
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int r = lane & 15, q = lane >> 4;
     const int b0 = blockIdx.x * a.imgs, cb = blockIdx.y;
-    const int nimg = min(a.imgs, a.B - b0);
+    const int nimg = BAND ? 1 : min(a.imgs, a.B - b0);
+    // the band (BAND) / the whole map
+    const int y0 = BAND ? (int)blockIdx.z * a.hb : 0;
+    const int nrow = BAND ? min(a.hb, a.H - y0) : a.H;
+    const int P = nimg * nrow * a.W;                                    // positions of this workgroup
+    const int grows = BAND ? 2 * nrow + 1 : a.OH;                       // gradient rows staged per channel
+    const int gstr = grows * a.OW;                                      // channel stride inside gimg
+    const int astr = nrow * a.W;                                        // channel stride inside araw
+    float* gimg = reinterpret_cast<float*>(cin4 + a.Cin);              // [imgs][Cout][gstr]   (16-byte aligned)
+    float* araw = gimg + ((nimg * a.Cout * gstr + 3) & ~3);            // [imgs][16][astr]     (16-byte aligned)
+    float* wl = araw + ((nimg * 16 * astr + 3) & ~3);                  // [16][wstr]
+    int* pos_g = reinterpret_cast<int*>(wl + 16 * a.wstr);             // [P] offset of (img, 2y, 2x) inside gimg
+    int* pos_a = pos_g + P;                                            // [P] offset of (img, pos) inside araw (channel 0)
+    int* pos_o = pos_a + P;                                            // [P] offset of (img, pos) inside gin (image b0, channel 0)
+    float* tiles = reinterpret_cast<float*>(pos_o + P);                // [waves][16 positions][17]
+#define CTB_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x < 384) a.dbg[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+    CTB_STAMP(0);
     const bool designated = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     const bool bwd = a.bn_out.mode == BN_BWD, act = a.bn_in.mode != BN_NONE;
-    const float inv_hw = 1.0f / (float)HW, inv_w = 1.0f / (float)a.W, inv_ohw = 1.0f / (float)OHW, inv_cout = 1.0f / (float)a.Cout;
+    const float inv_hw = 1.0f / (float)(nrow * a.W), inv_w = 1.0f / (float)a.W, inv_gstr = 1.0f / (float)gstr,
+                inv_cout = 1.0f / (float)a.Cout, inv_astr = 1.0f / (float)astr;
 
-    // ---- one burst: everything the workgroup reads, as 16-byte loads, requested before anything waits ----
-    // (Cout % 4 == 0 and 16 channels per block make every image's piece of each tensor a whole number of 16-byte pieces)
-    const int n_g4 = nimg * a.Cout * OHW / 4;
-    const f32x4* gsrc = reinterpret_cast<const f32x4*>(a.g + (size_t)b0 * a.Cout * OHW);
-    const f32x4* ysrc = bwd ? reinterpret_cast<const f32x4*>(a.yout + (size_t)b0 * a.Cout * OHW) : gsrc;
-    f32x4 gv[kCtbG4], yv[kCtbG4];
+    // ---- one burst: everything the workgroup reads, requested before anything waits ----
+    // whole maps: 16-byte loads (Cout % 4 == 0 and 16 channels per block make every image's piece of each tensor a whole
+    // number of 16-byte pieces); a band: 4-byte loads (its rows start anywhere)
+    constexpr int NG = BAND ? 8 : kCtbG4, NA = BAND ? 2 : kCtbA4;
+    using GT = typename std::conditional<BAND, float, f32x4>::type;
+    const int n_g = BAND ? a.Cout * gstr : nimg * a.Cout * OHW / 4;     // pieces
+    GT gv[NG], yv[NG];
+    if constexpr (BAND) {
+        const float* gb = a.g + ((size_t)b0 * a.Cout * a.OH + 2 * y0) * a.OW;
+        const float* yb = bwd ? a.yout + ((size_t)b0 * a.Cout * a.OH + 2 * y0) * a.OW : gb;
 #pragma unroll
-    for (int u = 0; u < kCtbG4; u++) {
-        const int i = min(tid + u * kCtbThreads, n_g4 - 1);
-        gv[u] = gsrc[i];
-        yv[u] = ysrc[i];
+        for (int u = 0; u < NG; u++) {
+            const int i = min(tid + u * kCtbThreads, n_g - 1);
+            const int co = div_small(i, inv_gstr), off = co * OHW + (i - co * gstr);
+            gv[u] = gb[off];
+            yv[u] = yb[off];
+        }
+    } else {
+        const f32x4* gsrc = reinterpret_cast<const f32x4*>(a.g + (size_t)b0 * a.Cout * OHW);
+        const f32x4* ysrc = bwd ? reinterpret_cast<const f32x4*>(a.yout + (size_t)b0 * a.Cout * OHW) : gsrc;
+#pragma unroll
+        for (int u = 0; u < NG; u++) {
+            const int i = min(tid + u * kCtbThreads, n_g - 1);
+            gv[u] = gsrc[i];
+            yv[u] = ysrc[i];
+        }
     }
-    const int n_a4 = 16 * HW / 4;   // per image
-    const float inv_na4 = 1.0f / (float)n_a4;
-    f32x4 av[kCtbA4];
+    const int n_a = BAND ? 16 * astr : nimg * 16 * HW / 4;              // pieces
+    GT av[NA];
+    if constexpr (BAND) {
+        const float* ab = a.ain + (((size_t)b0 * a.Cin + cb * 16) * a.H + y0) * a.W;
 #pragma unroll
-    for (int u = 0; u < kCtbA4; u++) {
-        const int i = min(tid + u * kCtbThreads, nimg * n_a4 - 1);
-        const int im = div_small(i, inv_na4), rem = i - im * n_a4;
-        av[u] = reinterpret_cast<const f32x4*>(a.ain + ((size_t)(b0 + im) * a.Cin + cb * 16) * HW)[rem];
+        for (int u = 0; u < NA; u++) {
+            const int i = min(tid + u * kCtbThreads, n_a - 1);
+            const int c = div_small(i, inv_astr);
+            av[u] = ab[c * HW + (i - c * astr)];
+        }
+    } else {
+        const int n_a4 = 16 * HW / 4;   // per image
+        const float inv_na4 = 1.0f / (float)n_a4;
+#pragma unroll
+        for (int u = 0; u < NA; u++) {
+            const int i = min(tid + u * kCtbThreads, n_a - 1);
+            const int im = div_small(i, inv_na4), rem = i - im * n_a4;
+            av[u] = reinterpret_cast<const f32x4*>(a.ain + ((size_t)(b0 + im) * a.Cin + cb * 16) * HW)[rem];
+        }
     }
     const int n_w4 = 16 * N / 4;
     f32x4 wr[kCtbW4];
@@ -111,9 +150,9 @@ __global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
         wr[u] = reinterpret_cast<const f32x4*>(a.w + (size_t)cb * 16 * N)[min(tid + u * kCtbThreads, n_w4 - 1)];
     // (keeps the compiler from sinking the loads into the predicated LDS stores below: load, wait, store, one by one)
 #pragma unroll
-    for (int u = 0; u < kCtbG4; u++) asm volatile("" : "+v"(gv[u]), "+v"(yv[u]));
+    for (int u = 0; u < NG; u++) asm volatile("" : "+v"(gv[u]), "+v"(yv[u]));
 #pragma unroll
-    for (int u = 0; u < kCtbA4; u++) asm volatile("" : "+v"(av[u]));
+    for (int u = 0; u < NA; u++) asm volatile("" : "+v"(av[u]));
 #pragma unroll
     for (int u = 0; u < kCtbW4; u++) asm volatile("" : "+v"(wr[u]));
     CTB_STAMP(1);
@@ -134,9 +173,9 @@ __global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
     if (tid < 32) lstat[tid] = 0.f;
     // the producer outputs, the weights and the position tables do not need the constants
 #pragma unroll
-    for (int u = 0; u < kCtbA4; u++) {
+    for (int u = 0; u < NA; u++) {
         const int i = tid + u * kCtbThreads;
-        if (i < nimg * n_a4) reinterpret_cast<f32x4*>(araw)[i] = av[u];
+        if (i < n_a) reinterpret_cast<GT*>(araw)[i] = av[u];
     }
     {
         const float inv_n = 1.0f / (float)N;
@@ -150,44 +189,54 @@ __global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
             }
         }
     }
-    for (int p = tid; p < nimg * HW; p += kCtbThreads) {
-        const int im = div_small(p, inv_hw), pi = p - im * HW;
+    for (int p = tid; p < P; p += kCtbThreads) {
+        const int im = div_small(p, inv_hw), pi = p - im * (nrow * a.W);   // pi: position inside the band / map
         const int y = div_small(pi, inv_w), x = pi - y * a.W;
-        pos_g[p] = im * a.Cout * OHW + 2 * y * a.OW + 2 * x;
-        pos_a[p] = im * 16 * HW + pi;
+        pos_g[p] = im * a.Cout * gstr + 2 * y * a.OW + 2 * x;
+        pos_a[p] = im * 16 * astr + pi;
+        pos_o[p] = im * a.Cin * HW + y0 * a.W + pi;
     }
     __syncthreads();
     CTB_STAMP(2);
-    // the gradient maps: BatchNorm-backward once per element (a 16-byte piece may straddle two channel planes)
+    // the gradient maps: BatchNorm-backward once per element
 #pragma unroll
-    for (int u = 0; u < kCtbG4; u++) {
+    for (int u = 0; u < NG; u++) {
         const int i = tid + u * kCtbThreads;
-        if (i < n_g4) {
-            f32x4 v = gv[u];
-            if (bwd) {
-                const int pl = div_small(4 * i, inv_ohw);          // plane (image * Cout + channel) of the first element
-                const int next = (pl + 1) * OHW;                    // first element of the next plane
-                const int co0 = pl - div_small(pl, inv_cout) * a.Cout;
-                const int co1 = co0 + 1 == a.Cout ? 0 : co0 + 1;
-                const float4 k0 = cout4[co0], k1 = cout4[co1];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float4 k = 4 * i + j >= next ? k1 : k0;
-                    v[j] = k.y * v[j] - k.z - (yv[u][j] - k.x) * k.w;
+        if (i < n_g) {
+            if constexpr (BAND) {
+                float v = gv[u];
+                if (bwd) {
+                    const float4 k = cout4[div_small(i, inv_gstr)];
+                    v = k.y * v - k.z - (yv[u] - k.x) * k.w;
                 }
+                gimg[i] = v;
+            } else {   // (a 16-byte piece may straddle two channel planes)
+                f32x4 v = gv[u];
+                if (bwd) {
+                    const int pl = div_small(4 * i, inv_gstr);         // plane (image * Cout + channel) of the first element
+                    const int next = (pl + 1) * gstr;                   // first element of the next plane
+                    const int co0 = pl - div_small(pl, inv_cout) * a.Cout;
+                    const int co1 = co0 + 1 == a.Cout ? 0 : co0 + 1;
+                    const float4 k0 = cout4[co0], k1 = cout4[co1];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float4 k = 4 * i + j >= next ? k1 : k0;
+                        v[j] = k.y * v[j] - k.z - (yv[u][j] - k.x) * k.w;
+                    }
+                }
+                reinterpret_cast<f32x4*>(gimg)[i] = v;
             }
-            reinterpret_cast<f32x4*>(gimg)[i] = v;
         }
     }
     __syncthreads();
     CTB_STAMP(3);
 
     // ---- tasks ----
-    const int P = nimg * HW;                                  // positions of this workgroup
     const int mtiles = (P + 15) >> 4;                         // input-gradient tasks: one tile of 16 positions each
     const int ntiles = (N + 15) >> 4;                         // weight-gradient tiles ...
-    const int kchunks = (P + kCtbKChunk - 1) / kCtbKChunk;    // ... times chunks of positions = weight-gradient tasks
-    const float4 kin = act ? cin4[cb * 16 + r] : make_float4(0.f, 0.f, 0.f, 0.f);   // lane r <-> channel cb*16 + r (both kinds of task)
+    constexpr int kChunk = kCtbKChunk;                        // (32 in band mode: more, smaller tasks - and twice the atomics: 171.0 against 169.2 us per step)
+    const int kchunks = (P + kChunk - 1) / kChunk;            // ... times chunks of positions = weight-gradient tasks
+    const float4 kin = act ? cin4[cb * 16 + r] : make_float4(0.f, 0.f, 0.f, 0.f);   // lane r <-> channel cb*16 + r (weight-gradient tasks)
     // input-gradient epilogue: lane (pl, cg) = position pl of the tile, channels cb*16 + 4 cg .. + 3
     const int pl = lane & 15, cg = lane >> 4;
     float4 kin4[4];
@@ -197,9 +246,11 @@ __global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
     float* tl = tiles + wv * (16 * 17);
     const float inv_kk = 1.0f / 9.0f, inv_3 = 1.0f / 3.0f;
     double* wacc_sh = a.wacc + (size_t)(blockIdx.x & (kStatShards - 1)) * a.wacc_stride;   // image groups spread over the shards
-    // (gridDim.z workgroups stage the same images and share the tasks: the staging is a fixed cost per workgroup, the tasks
-    // are what there is to spread over the chip)
-    for (int task = wv + kCtbWaves * blockIdx.z; task < mtiles + ntiles * kchunks; task += kCtbWaves * gridDim.z) {
+    float* gin0 = a.gin + ((size_t)b0 * a.Cin + cb * 16) * HW;
+    // whole maps: gridDim.z workgroups stage the same images and share the tasks (the staging is a fixed cost per workgroup,
+    // the tasks are what there is to spread over the chip); a band: all of its tasks
+    const int tfirst = BAND ? wv : wv + kCtbWaves * (int)blockIdx.z, tstep = BAND ? kCtbWaves : kCtbWaves * (int)gridDim.z;
+    for (int task = tfirst; task < mtiles + ntiles * kchunks; task += tstep) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = acc;
         if (task < mtiles) {
             // input gradient: rows = positions task*16 .. +15, columns = the 16 channels, K = Cout x (9 taps padded to 12)
@@ -222,7 +273,7 @@ __global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
                 float xa[4][3], xb[4][3];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const float* ac = ap + (co + c) * OHW;
+                    const float* ac = ap + (co + c) * gstr;
                     const float* bc = bp + (co + c) * KK;
 #pragma unroll
                     for (int ts = 0; ts < 3; ts++) {
@@ -241,25 +292,24 @@ __global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
                 }
             }
             // epilogue.  Register j of lane (r, q) is position task*16 + 4q + j, channel cb*16 + r: stored from that layout a
-            // store instruction touches 64 lines (the tensors are channel-major) - 230 k partial line writes per launch at
-            // the benchmark's third layer, and the kernel's end waits for them.  Transposed through the wave's own LDS tile a
-            // lane owns one position and four channels: 16 consecutive positions per instruction and channel.
+            // store instruction touches 64 lines (the tensors are channel-major).  Transposed through the wave's own LDS tile
+            // a lane owns one position and four channels: 16 consecutive positions per instruction and channel.
 #pragma unroll
             for (int j = 0; j < 4; j++) tl[(4 * q + j) * 17 + r] = acc[j] + acc1[j];
             const int pp = task * 16 + pl;
             if (pp < P) {
-                const int im = div_small(pp, inv_hw), pi = pp - im * HW;
+                const int oa = pos_a[pp], oo = pos_o[pp];
 #pragma unroll
                 for (int cc = 0; cc < 4; cc++) {
                     const int ch = 4 * cg + cc;
                     float v = tl[pl * 17 + ch];
                     if (act) {
-                        const float d = araw[im * 16 * HW + ch * HW + pi] - kin4[cc].x;
+                        const float d = araw[oa + ch * astr] - kin4[cc].x;
                         v = fmaf(d, kin4[cc].y, kin4[cc].z) > 0.f ? v : 0.f;
                         s1[cc] += v;
                         s2[cc] = fmaf(v, d * kin4[cc].w, s2[cc]);
                     }
-                    a.gin[((size_t)(b0 + im) * a.Cin + cb * 16 + ch) * HW + pi] = v;
+                    gin0[oo + ch * HW] = v;
                 }
             }
         } else {
@@ -271,9 +321,9 @@ __global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
             const int nc = n_ok ? n : 0;
             const int co = div_small(nc, inv_kk), tap = nc - co * KK;
             const int ky = div_small(tap, inv_3);
-            const float* gb = gimg + co * OHW + ky * a.OW + (tap - ky * 3);
-            const float* ar = araw + r * HW;
-            const int pbeg = kc * kCtbKChunk, pend = min(P, pbeg + kCtbKChunk);
+            const float* gb = gimg + co * gstr + ky * a.OW + (tap - ky * 3);
+            const float* ar = araw + r * astr;
+            const int pbeg = kc * kChunk, pend = min(P, pbeg + kChunk);
             // eight k-steps per trip: the table reads, then the operand reads, then eight MFMAs on two accumulators (one step
             // at a time the loop is a chain of two dependent LDS reads and an MFMA per step)
             for (int p0 = pbeg; p0 < pend; p0 += 32) {
@@ -337,6 +387,15 @@ __global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
     }
     CTB_STAMP(5);
 #undef CTB_STAMP
+}
+
+__global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_lds(CtBwd a) {
+    kernarg_warm<sizeof(CtBwd)>();
+    ct_bwd_body<false>(a);
+}
+__global__ void __launch_bounds__(kCtbThreads) k_ct_bwd_band(CtBwd a) {
+    kernarg_warm<sizeof(CtBwd)>();
+    ct_bwd_body<true>(a);
 }
 #endif   // CAE_CTBWD_KERNEL
 
