@@ -667,7 +667,9 @@ bool head_plan(const cae_engine* e, const StepArgs& a, HeadArgs& h, size_t& lds_
     h.momentum = kBnMomentum;
     h.eps = kBnEps;
     h.st = e->state();
-    static const int tpw = env_int("CAE_HEAD_TPW", 4);   // env: tuning only - Linear-3 column tiles per workgroup
+    // (1 since the end of round 2: 168.2 against 169.7 us per step with 4 - more workgroups recompute the encoder, each holds
+    // a quarter of the last Linear layer's weights and finishes its strip sooner; 8: 186.9)
+    static const int tpw = env_int("CAE_HEAD_TPW", 1);   // env: tuning only - Linear-3 column tiles per workgroup
     h.tiles_per_wg = tpw < 1 ? 1 : tpw;
     double* acc = e->gradacc();
     int64_t top = 0;
