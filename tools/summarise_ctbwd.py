@@ -33,7 +33,7 @@ def counters(path, key):
 def main():
     lines = [["kernel", "launches_per_step", "avg_us", "VALU_per_launch", "MFMA_per_launch", "VALU_per_MFMA", "VMEM_RD_per_launch",
               "LDS_per_launch", "fetch_MB_per_launch", "write_MB_per_launch"]]
-    for mode, key in (("0", "k_ig_bwd_pair"), ("7", "k_ct_bwd_lds")):
+    for mode, key in (("0", "k_ig_bwd_pair"), ("7", "k_ct_bwd")):   # k_ct_bwd_lds (whole images) and k_ct_bwd_band (the 16->8 layer)
         d = kernel_avgs(os.path.join(OUT, f"trace{mode}", "t_kernel_trace.csv"), key)
         c = counters(os.path.join(OUT, f"sq{mode}", "s_counter_collection.csv"), key)
         f = counters(os.path.join(OUT, f"fetch{mode}", "f_counter_collection.csv"), key)
