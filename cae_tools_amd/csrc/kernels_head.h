@@ -39,7 +39,7 @@ struct StageSplit {
     int lg, per;
 };
 
-constexpr int kHeadEarly = 5;   // of which requested at kernel start (k_head_fwd)
+constexpr int kHeadEarly = 4;   // of which requested at kernel start (k_head_fwd); 5: +0.4 us per step, 6: spills
 constexpr int kHeadW4 = 8;      // float4s of Linear weights a thread carries from kernel start to the LDS copy
 struct HeadW {
     const float* src;   // row-major [rows][4 * n4row]
