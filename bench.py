@@ -62,15 +62,11 @@ def circle_data(n, seed):
     return datagen.generate("circle", n, seed=seed)
 
 
-def packed(ds_train, ds=None):
-    """normalised, channel-packed device tensors (x, t) of `ds` with the training set's normalisation - DSDataset's GPU path"""
+def packed(ds_train, order):
+    """normalised, channel-packed device tensors (x, t) of the training set laid out in the frozen sample order - DSDataset's
+    GPU path (cae_scan_f32, cae_normalise_pack_rows), exactly what ConvAEModel.train hands the engine"""
     from cae_tools_amd.models.ds_dataset import DSDataset
-    tr = DSDataset(ds_train, ["lowres"], "hires")
-    if ds is None:
-        return tr.device_inputs(), tr.device_outputs()
-    te = DSDataset(ds, ["lowres"], "hires")
-    te.set_normalisation_parameters(tr.get_normalisation_parameters())
-    return te.device_inputs(), te.device_outputs()
+    return DSDataset(ds_train, ["lowres"], "hires").device_batches(order)
 
 
 def train_api_leg(ds_train, ds_test, epochs=20, test_interval=10):
@@ -169,6 +165,8 @@ def roofline_from_profile(recs, steps, trace_us=None):
     corrected_step = (total - overlap * overhead * sum(v[1] for v in agg.values())) / steps
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            # the same figure from the raw event bracket (no calibration file involved): a lower bound on the fraction
+            "achieved_bracketed": nbytes / (raw_us * 1e-6) / 1e9, "frac_bracketed": nbytes / (raw_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "kernel": label, "launches_per_step": count / steps, "avg_us": avg_us, "avg_us_bracketed": raw_us,
             "empty_event_pair_us": overhead, "bracket_overlap": overlap, "rocprofv3_avg_us": prof,
             "algorithmic_bytes_per_launch": nbytes, "share_of_step": us_sum / total}, table, corrected_step
@@ -218,11 +216,10 @@ def main():
     # every rank holds the same N_TRAIN samples and the same frozen shuffle (what ConvAEModel.train does under data
     # parallelism): a global batch is 64 * world consecutive rows of the permutation, rank r takes rows [64 r, 64 r + 64)
     ds_train = circle_data(N_TRAIN, 1234)
-    x, t = packed(ds_train)
     # the frozen shuffle, materialised once as ConvAEModel.train does (the reference stacks its shuffled batches once and
-    # reuses the list every epoch, conv_ae_model.py:315-325): batches are contiguous rows, no permutation look-up in the step
-    order = torch.as_tensor(np.random.default_rng(99).permutation(N_TRAIN), device=device)
-    (x, t) = (x.index_select(0, order), t.index_select(0, order))
+    # reuses the list every epoch, conv_ae_model.py:315-325) - by the normalisation kernel, which writes every sample to its
+    # row of the frozen order: batches are contiguous rows, no permutation look-up in the step, no second copy of the data
+    x, t = packed(ds_train, np.random.default_rng(99).permutation(N_TRAIN))
     eng.set_dataset(0, x, t)
     perm = None
     global_batch = BATCH * world
@@ -284,6 +281,12 @@ def main():
         if dist is not None:
             dist.barrier(device_ids=[local_rank])
 
+    # every hipGraph shape the warm-up and the timed steps will replay is captured here, launching nothing: the timed
+    # region then holds exactly K steps of work and no graph instantiation (a K-step graph is a different shape than a W-step one)
+    if hasattr(eng, "capture_graphs") and (dist is None or native):
+        with eng.capture_graphs():
+            run(args.warmup)
+            run(args.steps)
     run(args.warmup)
     eng.sync()
     torch.cuda.synchronize(device)
@@ -303,6 +306,12 @@ def main():
     eng._read_losses(0, min(steps_per_epoch, eng.loss_slots))  # drain loss slots (outside the timed region)
 
     result = None
+    dp_info = (None, None, None)
+    if dist is not None and native:
+        import ctypes
+        (w_, r_, g_) = (ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0))
+        eng.lib.cae_dp_info(eng.handle, ctypes.byref(w_), ctypes.byref(r_), ctypes.byref(g_))
+        dp_info = (int(w_.value), int(r_.value), bool(g_.value))
     if rank == 0:
         value = BATCH * world * args.steps / elapsed
         result = {
@@ -322,7 +331,14 @@ def main():
                          "RCCL all-reduce of 2 gradient buckets and of every BatchNorm sum table on the main stream") +
                         (", captured in the step graph" if dp_graph else ", plain launches")),
                        "dp_calibration_us_per_step": None if dist is None else
-                       {k: round(v * 1e6, 1) for k, v in dp_times.items()}},
+                       {k: round(v * 1e6, 1) for k, v in dp_times.items()},
+                       # what the library's own communicator reports (cae_dp_info): did RCCL see N ranks, are the
+                       # collectives inside the captured step graph, which exchange structure the calibration kept
+                       "dp_world": dp_info[0], "dp_rank0": dp_info[1], "dp_graph_capture": dp_info[2],
+                       "dp_structure": None if dist is None or not native else
+                       ("syncbn" if args.sync_bn else ("overlap: bucket 0 on the second stream" if eng.dp_overlap else
+                                                       "serial: one all-reduce after backward")),
+                       "steps_per_graph_replay": min(steps_per_epoch, args.steps)},
             "step_roofline": {"algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE,
                               "achieved_GBs": value / world * ALGO_BYTES_PER_IMAGE / 1e9,
                               "frac_of_8TBs": value / world * ALGO_BYTES_PER_IMAGE / 1e9 / HBM_PEAK_GBS},

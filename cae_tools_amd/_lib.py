@@ -45,6 +45,7 @@ SIGNATURES = {
     "cae_set_stream": (C.c_int, [_P, _P]),
     "cae_set_graph_mode": (C.c_int, [_P, C.c_int]),
     "cae_set_kernel_mode": (C.c_int, [_P, C.c_int]),
+    "cae_set_capture_only": (C.c_int, [_P, C.c_int]),
     "cae_set_hyper": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     "cae_set_dataset": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
     "cae_set_cursor": (C.c_int, [_P, C.c_int64, C.c_int]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "cae_read_losses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cae_loss_slots": (C.c_int, [_P]),
     "cae_sync": (C.c_int, [_P]),
+    "cae_graph_count": (C.c_int, [_P]),
     "cae_debug_read": (C.c_int64, [_P, C.c_char_p, C.c_int, _P, C.c_int64]),
     "cae_profile_begin": (C.c_int, [_P]),
     "cae_debug_launch_floor": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
@@ -79,6 +81,9 @@ SIGNATURES = {
     "cae_scan_f32": (C.c_int, [_P, C.c_int64, _P, C.POINTER(C.c_double)]),
     "cae_normalise_pack": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_float,
                                      C.c_float, C.c_int, _P]),
+    "cae_normalise_pack_rows": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_float,
+                                          C.c_float, C.c_int, _P, _P]),
+    "cae_invert_permutation": (C.c_int, [_P, C.c_int64, _P, _P]),
     "cae_denormalise_f64": (C.c_int, [_P, C.c_int64, C.c_double, C.c_double, _P, _P]),
     "cae_bswap32": (C.c_int, [_P, C.c_int64, _P]),
     "cae_metric_sums": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, _P, _P]),

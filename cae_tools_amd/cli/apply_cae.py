@@ -35,6 +35,8 @@ def main(argv=None):
         if rc:
             raise SystemExit(rc)
         return
+    from .. import dp as _dp
+    _dp.select_device()     # inside a rank: LOCAL_RANK's GPU before the first allocation
     with open(os.path.join(args.model_folder, "parameters.json")) as f:
         parameters = json.loads(f.read())
     kinds = {"ConvAEModel": ConvAEModel, "UNET": UNET, "VarAEModel": VarAEModel, "LinearModel": LinearModel}

@@ -81,11 +81,23 @@ def broadcast_case_variables(ds, variables, case_dimension):
 def main(argv=None):
     args = build_parser().parse_args(argv)
     from ._launch import maybe_spawn_ranks
+    from .. import dp as _dp
+    if max(int(args.gpus or 1), _dp.env_world()[2]) > 1:
+        # only ConvAEModel has a data-parallel training path: any other model under N ranks would be trained N times
+        # independently, all ranks writing the same model folder and database.  Decided BEFORE ranks are spawned.
+        kind = "ConvAEModel" if args.method == "conv" else args.method
+        if args.continue_training:
+            with open(os.path.join(args.model_folder, "parameters.json")) as f:
+                kind = json.loads(f.read()).get("type")
+        if kind != "ConvAEModel":
+            raise SystemExit(f"--gpus {args.gpus}: data-parallel training is implemented for --method conv (ConvAEModel) only; "
+                             f"this run would train a '{kind}' model - use --gpus 1")
     rc = maybe_spawn_ranks("cae_tools_amd.cli.train_cae", args.gpus, argv)   # before anything touches the GPU
     if rc is not None:
         if rc:
             raise SystemExit(rc)
         return
+    _dp.select_device()     # inside a rank: LOCAL_RANK's GPU before the first allocation
     train_ds = open_mfdataset(args.train_inputs, concat_dim="box", combine="nested")
     test_ds = open_mfdataset(args.test_inputs, concat_dim="box", combine="nested")
     case_dimension = train_ds[args.output_variable].dims[0]

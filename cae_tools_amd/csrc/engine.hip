@@ -126,7 +126,9 @@ struct cae_engine {
     const float* ds_t[2] = {nullptr, nullptr};
     int64_t ds_n[2] = {0, 0};
     bool graph_mode = true;
+    bool capture_only = false;   // cae_set_capture_only: step calls capture + cache their graph and launch nothing
     bool use_s2 = true;  // specialised stride-2 kernels (cae_set_kernel_mode)
+    bool gather_fwd = false;   // cae_set_kernel_mode bit 2: channel-rich decoder layers' forward on the gather kernel k_ig_fwd_s2
     int ctbwd_mask = 0;  // bit l: decoder layer l's backward runs the LDS-staged kernel (kernels_ctbwd.h) where eligible
     int ctbwd_auto = 0;  // ... the mask chosen at creation (CAE_CTBWD, or the rule in cae_create): its layers have sharded accumulators
     int64_t off_xbatch = 0;     // the current batch's inputs, contiguous (written by k_head_fwd, read by k_adam's fused conv-0 weight gradient)
@@ -136,8 +138,9 @@ struct cae_engine {
     bool profiling = false;
     struct ProfRec { const char* name; int layer; double bytes; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof;
-    // key: (op, which, batch, global_batch, perm)
-    std::map<std::tuple<int, int, int, int, const void*, int, int>, hipGraphExec_t> graphs;
+    // key: (op, which, batch, global_batch, perm, nsteps, cursor_inc, BatchNorm mode = (dp_sync, bn_batch, world)): everything
+    // a captured launch sequence bakes in that is not engine-wide state (engine-wide changes call drop_graphs())
+    std::map<std::tuple<int, int, int, int, const void*, int, int, int, int, int>, hipGraphExec_t> graphs;
 
     // data-parallel state (cae_dp_init): one RCCL communicator, a second stream for the gradient buckets, fork/join events
     int dp_world = 0, dp_rank = 0;
@@ -624,7 +627,7 @@ bool ct_fwd_launch(cae_engine* e, const StepArgs& a, const ConvLayer& L, int lay
     // both take 8-11 us per launch, all of it latency, and the step is 0.8 us shorter with the gather kernels (167.7 against
     // 168.5, four alternating runs) - but their gradients at that size sit 6.8e-4 from the oracle's where the LDS-staged
     // forward's sit within the full-size test's 2e-4 (test_full_size_gpu.py): parity first, the LDS-staged kernels run.
-    const int mask = enabled >= 0 ? enabled : 0x7fffffff;
+    const int mask = e->gather_fwd ? 0 : (enabled >= 0 ? enabled : 0x7fffffff);
     if (!(layer < 31 && ((mask >> layer) & 1)) || L.cin % 4 || L.kh < 3 || L.kw < 3) return false;
     CtFwd c;
     memset(&c, 0, sizeof c);
@@ -1156,7 +1159,7 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
             const int per_block = (4 / f.ksplit) * f.tiles_per_wave;
             dim3 grid((mtiles + per_block - 1) / per_block, 4, (L.cout + 15) / 16);
             ProfScope _p(e, a.train ? "ig_convt_fwd" : "ig_convt_eval", (int)l, f4((double)B * (L.in_elems() + L.out_elems())));
-            hipLaunchKernelGGL(k_ig_fwd_s2, grid, dim3(256), (32 + 1024) * sizeof(float) + (size_t)(L.cin + 1) * sizeof(float4), s, f);
+            hipLaunchKernelGGL(k_ig_fwd_s2, grid, dim3(256), (64 + 1024) * sizeof(float) + (size_t)(L.cin + 1) * sizeof(float4), s, f);
             if (a.train)
                 if (int rc = sync_bn_table(e, a, L.bn_index)) return rc;
             continue;
@@ -1763,8 +1766,12 @@ int launch_one(cae_engine* e, int op, const StepArgs& a) {
 // run an op either directly or through a cached hipGraph
 int run_op(cae_engine* e, int op, const StepArgs& a, bool cacheable) {
     // the legacy NULL stream cannot be captured: plain launches there
-    if (!e->graph_mode || !cacheable || e->stream == nullptr || e->profiling) return launch_op(e, op, a);
-    auto key = std::make_tuple(op, a.which, a.batch, a.global_batch, (const void*)a.perm, a.nsteps, a.cursor_inc);
+    if (!e->graph_mode || !cacheable || e->stream == nullptr || e->profiling)
+        return e->capture_only ? CAE_OK : launch_op(e, op, a);
+    // a SyncBN step and a per-rank-BatchNorm step of the same sizes are DIFFERENT launch sequences (table all-reduces,
+    // bn_batch in every BatchNorm descriptor, the 1/world scale of the BatchNorm parameter gradients)
+    auto key = std::make_tuple(op, a.which, a.batch, a.global_batch, (const void*)a.perm, a.nsteps, a.cursor_inc,
+                               a.dp_sync ? 1 : 0, a.bn_batch, a.world);
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -1782,6 +1789,7 @@ int run_op(cae_engine* e, int op, const StepArgs& a, bool cacheable) {
         if (ie != hipSuccess) return fail(CAE_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
         it = e->graphs.emplace(key, exec).first;
     }
+    if (e->capture_only) return CAE_OK;
     HIP_TRY(hipGraphLaunch(it->second, e->stream));
     return CAE_OK;
 }
@@ -2049,13 +2057,21 @@ int cae_set_graph_mode(cae_engine* e, int enabled) {
     return CAE_OK;
 }
 
+int cae_set_capture_only(cae_engine* e, int enabled) {
+    if (!e) return fail(CAE_ERR_ARG, "null engine");
+    e->capture_only = enabled != 0;
+    return CAE_OK;
+}
+
 int cae_set_kernel_mode(cae_engine* e, int specialised) {
     if (!e) return fail(CAE_ERR_ARG, "null engine");
     static const int force_env = env_int("CAE_CTBWD_FORCE", -1);   // env: A/B measurements only - run-time mask (unsharded where not chosen at creation)
     const int ctb = (specialised & 2) ? 0x7fffffff : (force_env >= 0 ? force_env : e->ctbwd_auto);   // bit 1: every eligible layer
-    if (e->use_s2 != ((specialised & 1) != 0) || ctb != e->ctbwd_mask) e->drop_graphs();
+    const bool gather = (specialised & 4) != 0;
+    if (e->use_s2 != ((specialised & 1) != 0) || ctb != e->ctbwd_mask || gather != e->gather_fwd) e->drop_graphs();
     e->use_s2 = (specialised & 1) != 0;
     e->ctbwd_mask = ctb;
+    e->gather_fwd = gather;
     return CAE_OK;
 }
 
@@ -2318,6 +2334,7 @@ int cae_dp_eval_steps(cae_engine* e, int which, const int32_t* perm, int batch, 
     if (nsteps < 1 || nsteps > 4096) return fail(CAE_ERR_ARG, "nsteps %d outside [1, 4096]", nsteps);
     if (batch == 0) {   // empty shard: only the cursor and the loss slot move
         if (!e->ws) return fail(CAE_ERR_STATE, "cae_bind has not been called");
+        if (e->capture_only) return CAE_OK;
         for (int i = 0; i < nsteps; i++) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, e->stream, e->state(), global_batch, 1, 0);
         HIP_TRY(hipGetLastError());
         return CAE_OK;
@@ -2402,6 +2419,8 @@ int cae_sync(cae_engine* e) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     return CAE_OK;
 }
+
+int cae_graph_count(const cae_engine* e) { return e ? (int)e->graphs.size() : 0; }
 
 int64_t cae_debug_read(cae_engine* e, const char* what, int index, void* host_out, int64_t cap) {
     if (!e || !e->ws || !what || !host_out) return fail(CAE_ERR_ARG, "cae_debug_read: bad argument");
@@ -2547,15 +2566,29 @@ int cae_scan_f32(const float* x, int64_t n, void* hip_stream, double* out3) {
     return CAE_OK;
 }
 
-int cae_normalise_pack(const float* src, int64_t n, int c_src, int64_t hw, float* dst, int c_dst, int c_off,
-                       float vmin, float range, int enable, void* hip_stream) {
+int cae_normalise_pack_rows(const float* src, int64_t n, int c_src, int64_t hw, float* dst, int c_dst, int c_off,
+                            float vmin, float range, int enable, const int32_t* dst_row_dev, void* hip_stream) {
     if (!src || !dst || n < 1 || c_src < 1 || hw < 1 || c_off < 0 || c_off + c_src > c_dst)
         return fail(CAE_ERR_ARG, "cae_normalise_pack: bad argument");
+    if (n > 0x7fffffffLL) return fail(CAE_ERR_ARG, "cae_normalise_pack: more than 2^31 - 1 rows");
     const long long total = (long long)n * c_src * hw;
     int blocks = (int)((total + 256 * 8 - 1) / (256 * 8));
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_normalise_pack, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream, src, total, c_src,
-                       (long long)hw, dst, c_dst, c_off, vmin, range, enable);
+                       (long long)hw, dst, c_dst, c_off, vmin, range, enable, (const int*)dst_row_dev);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_normalise_pack(const float* src, int64_t n, int c_src, int64_t hw, float* dst, int c_dst, int c_off,
+                       float vmin, float range, int enable, void* hip_stream) {
+    return cae_normalise_pack_rows(src, n, c_src, hw, dst, c_dst, c_off, vmin, range, enable, nullptr, hip_stream);
+}
+
+int cae_invert_permutation(const int32_t* perm_dev, int64_t n, int32_t* inverse_dev, void* hip_stream) {
+    if (!perm_dev || !inverse_dev || n < 1 || n > 0x7fffffffLL) return fail(CAE_ERR_ARG, "cae_invert_permutation: bad argument");
+    hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                       (const int*)perm_dev, (long long)n, (int*)inverse_dev);
     HIP_TRY(hipGetLastError());
     return CAE_OK;
 }

@@ -1123,16 +1123,29 @@ __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ x, long 
     }
 }
 
-// dst[i][c_off + c][:] = (src[i][c][:] - vmin) / range   (two correctly rounded fp32 ops, as numpy)
+// dst[row(i)][c_off + c][:] = (src[i][c][:] - vmin) / range   (two correctly rounded fp32 ops, as numpy)
+// row(i) = dst_row[i] when a table is given (the frozen shuffle's inverse: normalisation writes the samples in batch order
+// in the pass it makes anyway - the reference's DataLoader + collate stacking, conv_ae_model.py:291-292,315-325), else i.
 __global__ void __launch_bounds__(256) k_normalise_pack(const float* __restrict__ src, long long total, int c_src,
                                                          long long hw, float* __restrict__ dst, int c_dst, int c_off,
-                                                         float vmin, float range, int enable) {
+                                                         float vmin, float range, int enable,
+                                                         const int* __restrict__ dst_row) {
+    const long long per = (long long)c_src * hw;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long per = (long long)c_src * hw;
         const long long s = i / per, r = i - s * per;
         float v = src[i];
         if (enable) v = (range == 0.f) ? 0.f : __fdiv_rn(__fsub_rn(v, vmin), range);
-        dst[(s * c_dst + c_off) * hw + r] = v;
+        const long long d = dst_row ? (long long)dst_row[s] : s;
+        dst[(d * c_dst + c_off) * hw + r] = v;
+    }
+}
+
+// inv[perm[i]] = i: the destination-row table of k_normalise_pack from a frozen sample order
+__global__ void __launch_bounds__(256) k_invert_perm(const int* __restrict__ perm, long long n, int* __restrict__ inv) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int p = perm[i];
+        if (p >= 0 && p < n) inv[p] = (int)i;
     }
 }
 

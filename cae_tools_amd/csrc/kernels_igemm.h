@@ -50,11 +50,11 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
 #define IG_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) a.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
     extern __shared__ double lds_d[];
     IG_STAMP(0);
-    float* lstat = reinterpret_cast<float*>(lds_d);  // [16 channels][2]
-    float* part = lstat + 32;                        // [4 waves][256] split-K partial tiles
+    double* lstat = lds_d;                           // [16 channels][2], fp64: see the statistics epilogue
+    float* part = reinterpret_cast<float*>(lds_d + 32);   // [4 waves][256] split-K partial tiles
     float4* cin4 = reinterpret_cast<float4*>(part + 1024);
     bn_consts(a.bn_in, cin4, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
-    if (threadIdx.x < 32) lstat[threadIdx.x] = 0.f;
+    if (threadIdx.x < 32) lstat[threadIdx.x] = 0.0;
     __syncthreads();
     IG_STAMP(1);
 
@@ -207,19 +207,24 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
     }
     IG_STAMP(3);
     if (a.stats) {
+        // A lane's fp32 sums cover 4 * tiles_per_wave values; from there on fp64 (as k_ct_fwd_lds does).  Until round 3 the
+        // fold over lane groups and waves ran in fp32 (64 * tiles_per_wave values per channel and workgroup): var = E[y^2] -
+        // mean^2 amplifies that rounding by mean^2 / var, and at the benchmark batch this kernel's gradients sat 6.8e-4 from
+        // the oracle's where the LDS-staged forward's sit within 2e-4 (tests/test_full_size_gpu.py).
         // lanes r, r+16, r+32, r+48 hold the same channel: fold, then LDS, then one fp64 atomic per value
-        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        double d1 = (double)s1, d2 = (double)s2;
+        d1 += __shfl_xor(d1, 16, 64); d2 += __shfl_xor(d2, 16, 64);
+        d1 += __shfl_xor(d1, 32, 64); d2 += __shfl_xor(d2, 32, 64);
         if (q == 0 && co < a.Cout) {
-            atomicAdd(&lstat[2 * r], s1);
-            atomicAdd(&lstat[2 * r + 1], s2);
+            atomicAdd(&lstat[2 * r], d1);
+            atomicAdd(&lstat[2 * r + 1], d2);
         }
         __syncthreads();
         if (threadIdx.x < 32) {
             const int c = blockIdx.z * 16 + (threadIdx.x >> 1);
             if (c < a.Cout) {
                 const int shard = (blockIdx.x + blockIdx.y) & (kStatShards - 1);
-                atomicAdd(&a.stats[((size_t)shard * a.Cout + c) * 4 + (threadIdx.x & 1)], (double)lstat[threadIdx.x]);
+                atomicAdd(&a.stats[((size_t)shard * a.Cout + c) * 4 + (threadIdx.x & 1)], lstat[threadIdx.x]);
             }
         }
         IG_STAMP(4);

@@ -52,9 +52,16 @@ class DataParallel:
             engine.dp_set_overlap(bool(overlap))
 
     def _calibrate(self, which, perm, start, batch, global_batch):
-        if self.native and self.overlap == "auto" and self.calibration is None and not self.sync_bn and batch > 0:
-            self.calibration = self.engine.dp_calibrate(self.dist, which, perm, start, batch, global_batch, False,
-                                                        group=self.group)
+        """dp_calibrate is COLLECTIVE (RCCL steps + an all-reduce of the timings), so whether it runs is decided from values
+        every rank shares: a global batch smaller than the world leaves some rank's shard empty, and then no rank calibrates
+        (the default structure stays) rather than some entering the collective and the others not."""
+        if not (self.native and self.overlap == "auto" and self.calibration is None and not self.sync_bn):
+            return
+        if int(global_batch) < self.world:
+            self.calibration = {}
+            return
+        self.calibration = self.engine.dp_calibrate(self.dist, which, perm, start, batch, global_batch, False,
+                                                    group=self.group)
 
     def _stream_ctx(self):
         stream = getattr(self.engine, "stream", None)
@@ -138,11 +145,11 @@ class DataParallel:
             eng.set_cursor(lo, first)      # the device cursor then moves one global batch per step
             left = full
             per_graph = getattr(eng, "STEPS_PER_GRAPH", 64)
-            while left >= per_graph:       # only two graph shapes per batch size (K steps, 1 step)
+            while left >= per_graph:       # three graph shapes per batch size at most: K steps, the remainder, 1 step
                 steps(hi - lo, global_batch, per_graph)
                 left -= per_graph
-            for _ in range(left):
-                steps(hi - lo, global_batch, 1)
+            if left:
+                steps(hi - lo, global_batch, left)
         if rem:
             (lo, hi) = shard_bounds(rem, self.world, self.rank)
             eng.set_cursor(full * global_batch + lo, first + full)
@@ -183,11 +190,23 @@ def env_world():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def select_device():
+    """Make LOCAL_RANK's GPU the current device of a rank of a torch.distributed.run launch.  Every entry point that may
+    run in a rank (train / apply / evaluate, the CLIs) calls this BEFORE its first CUDA allocation: DSDataset and the
+    engines allocate on torch.cuda.current_device(), which is 0 in every rank until somebody says otherwise, and an engine
+    on GPU r must not be handed GPU-0 pointers.  No-op outside a launch and without a GPU.  Returns the local rank."""
+    (rank, local_rank, world) = env_world()
+    if world > 1 and torch.cuda.is_available() and torch.cuda.current_device() != local_rank:
+        torch.cuda.set_device(local_rank)
+    return local_rank
+
+
 def ensure_process_group():
     """torch.distributed handle when this process is one rank of a torch.distributed.run launch (initialising the
     default group on first use: RCCL when a GPU is present), else None.  The GPU of a rank is LOCAL_RANK."""
     import os
     import torch.distributed as dist
+    select_device()
     if dist.is_available() and dist.is_initialized():
         # CAE_FORCE_DP=1: take the data-parallel code path on a one-rank group too (rehearsal on a one-GPU box and in tests)
         return dist if dist.get_world_size() > 1 or os.environ.get("CAE_FORCE_DP") == "1" else None

@@ -196,6 +196,12 @@ class HipEngine(EnginePlan):
                                      float(weight_decay)))
 
     # ---- data ------------------------------------------------------------------------------
+    def _same_device(self, a, what):
+        """the kernels dereference plain pointers: a tensor on another GPU is a memory fault, not a slow path"""
+        if a.device != self.device:
+            raise CaeError(f"{what} lives on {a.device} but this engine runs on {self.device} "
+                           "(select the rank's GPU before creating data sets: cae_tools_amd.dp.select_device)")
+
     def set_dataset(self, which, x, t=None):
         """x (N,C,H,W) / t (N,C,H,W): fp32 CUDA tensors, already normalised; kept alive here"""
         for name, a, shp in (("x", x, self.in_shape), ("t", t, self.out_shape)):
@@ -203,6 +209,7 @@ class HipEngine(EnginePlan):
                 continue
             if a.dtype != torch.float32 or not a.is_cuda or not a.is_contiguous():
                 raise CaeError(f"dataset {name} must be a contiguous fp32 CUDA tensor")
+            self._same_device(a, f"dataset {name}")
             if tuple(a.shape[1:]) != tuple(shp):
                 raise CaeError(f"dataset {name} has sample shape {tuple(a.shape[1:])}, model expects {tuple(shp)}")
         self.sync()
@@ -269,14 +276,38 @@ class HipEngine(EnginePlan):
         many = self.lib.cae_train_steps if train else self.lib.cae_eval_steps
         one = self.lib.cae_train_step if train else self.lib.cae_eval_step
         full = n // batch_size
-        # only two graph shapes per batch size (K steps, 1 step), so nothing is captured mid-run
+        # at most three graph shapes per (data set, batch size): K steps, the remainder of the full batches, the partial
+        # batch - all met in the first epoch, so nothing is captured mid-run (capture_graphs() builds them ahead of it)
         while full >= self.STEPS_PER_GRAPH:
             check(many(self.handle, which, ptr, batch_size, self.STEPS_PER_GRAPH))
             full -= self.STEPS_PER_GRAPH
-        for _ in range(full):
+        if full > 1:
+            check(many(self.handle, which, ptr, batch_size, full))
+        elif full == 1:
             check(one(self.handle, which, ptr, batch_size))
         if n % batch_size:
             check(one(self.handle, which, ptr, n % batch_size))
+
+    def capture_graphs(self):
+        """Context manager: step calls made inside capture and cache their hipGraphs and launch nothing
+        (cae_set_capture_only); the host-side counters are put back on exit.  Used to build every graph shape of an epoch
+        loop before its first (timed) step."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            keep = (self.num_batches_tracked, self.adam_steps, self._slot, self._cursor)
+            check(self.lib.cae_set_capture_only(self.handle, 1))
+            try:
+                yield self
+            finally:
+                check(self.lib.cae_set_capture_only(self.handle, 0))
+                (self.num_batches_tracked, self.adam_steps, self._slot, _) = keep
+                self._cursor = None     # cae_set_cursor is not a step function: the device cursor may have moved
+        return scope()
+
+    def graph_count(self):
+        return int(self.lib.cae_graph_count(self.handle))
 
     def train_step(self, which, perm_dev, start, size):
         """a single training step on perm[start:start+size]; returns its loss (blocking)"""
@@ -456,6 +487,7 @@ class HipEngine(EnginePlan):
         """eval-mode forward of an explicit batch (B,C,H,W) fp32 CUDA tensor -> (B,C,H,W)"""
         if x.dtype != torch.float32 or not x.is_cuda:
             raise CaeError("score() needs an fp32 CUDA tensor")
+        self._same_device(x, "score() input")
         x = x.contiguous()
         out = torch.empty((x.shape[0],) + tuple(self.out_shape), dtype=torch.float32, device=self.device)
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -472,6 +504,7 @@ class HipEngine(EnginePlan):
     def _module_forward(self, fn, x, row_shape, what):
         if x.dtype != torch.float32 or not x.is_cuda:
             raise CaeError(f"{what}() needs an fp32 CUDA tensor")
+        self._same_device(x, f"{what}() input")
         x = x.contiguous()
         out = torch.empty((x.shape[0],) + tuple(row_shape), dtype=torch.float32, device=self.device)
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -532,16 +565,39 @@ def scan_f32(x):
     return int(out[0]), float(out[1]), float(out[2])
 
 
-def normalise_pack(src, dst, c_off, vmin, vmax, enable=True):
-    """dst[:, c_off:c_off+Cv] = normalise(src) on the device (ds_dataset.py:99-113,137-147).
-    The range is formed in fp64 from python floats and rounded to fp32, as numpy does."""
+def normalise_pack(src, dst, c_off, vmin, vmax, enable=True, dst_rows=None):
+    """dst[row(i), c_off:c_off+Cv] = normalise(src[i]) on the device (ds_dataset.py:99-113,137-147).
+    The range is formed in fp64 from python floats and rounded to fp32, as numpy does.
+    dst_rows: int32 CUDA tensor, row(i) = dst_rows[i] (inverse_permutation() of a frozen sample order: the samples land in
+    batch order, which is the DataLoader + collate stacking of conv_ae_model.py:291-292,315-325); None: row(i) = i."""
     lib = _lib.load()
     (n, c_src) = (int(src.shape[0]), int(src.shape[1]))
     hw = int(np.prod(src.shape[2:]))
     rng = float(vmax) - float(vmin)
-    check(lib.cae_normalise_pack(src.data_ptr(), n, c_src, hw, dst.data_ptr(), int(dst.shape[1]), int(c_off),
-                                 C.c_float(float(np.float32(vmin))), C.c_float(float(np.float32(rng))),
-                                 1 if enable else 0, torch.cuda.current_stream(src.device).cuda_stream))
+    if dst_rows is not None:
+        if dst_rows.dtype != torch.int32 or dst_rows.device != src.device or dst_rows.numel() != n or int(dst.shape[0]) != n:
+            raise CaeError("normalise_pack: dst_rows must be an int32 tensor of one entry per sample on the data's device")
+    with torch.cuda.device(src.device):
+        check(lib.cae_normalise_pack_rows(src.data_ptr(), n, c_src, hw, dst.data_ptr(), int(dst.shape[1]), int(c_off),
+                                          C.c_float(float(np.float32(vmin))), C.c_float(float(np.float32(rng))),
+                                          1 if enable else 0, dst_rows.data_ptr() if dst_rows is not None else None,
+                                          torch.cuda.current_stream(src.device).cuda_stream))
+
+
+def inverse_permutation(order, device):
+    """int32 CUDA tensor inv with inv[order[i]] = i (cae_invert_permutation): where each sample goes when the data set is
+    laid out in the frozen order `order` (host sequence of sample indices, every index exactly once)."""
+    lib = _lib.load()
+    order = np.ascontiguousarray(np.asarray(order, dtype=np.int32))
+    n = int(order.size)
+    if n < 1 or not np.array_equal(np.sort(order), np.arange(n, dtype=np.int32)):
+        raise CaeError("inverse_permutation: `order` must hold every sample index 0..n-1 exactly once")
+    perm = torch.from_numpy(order).to(device)
+    inv = torch.empty(n, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        check(lib.cae_invert_permutation(perm.data_ptr(), n, inv.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
+    torch.cuda.synchronize(device)
+    return inv
 
 
 def denormalise_f64(y, vmin, vmax):

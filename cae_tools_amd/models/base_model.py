@@ -87,6 +87,8 @@ class BaseModel:
         stay on the GPU; cae_metric_sums reduces each case to eight fp64 sums.  The mask is all ones unless the
         dataset carries a mask variable shaped like the output (the reference builds the default mask with the
         INPUT's shape, which cannot index the output; the intended all-pixels mask is used - SURVEY.md headline 3)."""
+        from .. import dp as _dp
+        _dp.select_device()
         dataset.set_normalise_output(False)
         truth = dataset.device_outputs()
         scores = self._score_all(dataset.device_inputs())
@@ -99,6 +101,8 @@ class BaseModel:
               x_dimension="model_output_x", mask_variable_name=None):
         """Add `prediction_variable` (float64, denormalised, dims (case, channel, y, x)) to score_ds
         in place (:102-152)."""
+        from .. import dp as _dp
+        _dp.ensure_process_group()      # a rank's GPU is selected before the data set is uploaded
         first = score_ds[input_variables[0]]
         n_dimension = first.dims[0]
         ds = DSDataset(score_ds, input_variables, input_variables[0], normalise_in=self.normalise_input,

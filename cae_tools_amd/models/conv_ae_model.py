@@ -176,6 +176,9 @@ class ConvAEModel(BaseModel):
         """Train (or continue training): see the reference docstring (:241-252).  Data flow: both
         datasets are scanned / normalised / packed on the GPU once, the shuffle is frozen once
         (:315-325), and every epoch is nb calls of cae_train_step plus one loss read-back."""
+        # a rank of a torch.distributed.run launch works on ITS GPU from the first allocation on (the data sets below
+        # are uploaded to the current device, the engine is created on it)
+        dist = _dp.ensure_process_group()
         train_ds = DSDataset(training_ds, input_variables, output_variable,
                              normalise_in=self.normalise_input, normalise_out=self.normalise_output)
         self.normalisation_parameters = train_ds.get_normalisation_parameters()
@@ -207,7 +210,6 @@ class ConvAEModel(BaseModel):
         # Data parallel (build-only; the reference selects ONE device at :294-297 and moves the modules there at :312-313):
         # under a torch.distributed.run launch every rank holds the model and both data sets, takes its rows of each frozen
         # GLOBAL batch (dp.shard_bounds) and the gradients are all-reduced inside libcae_hip; rank 0 prints and saves.
-        dist = _dp.ensure_process_group()
         (world, rank) = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
         lead = rank == 0
         if dist is not None:    # one frozen shuffle for everybody: rank 0's draw
@@ -223,14 +225,12 @@ class ConvAEModel(BaseModel):
         eng.set_hyper(lr=self.lr, weight_decay=self.weight_decay)
         eng.reset_optimizer()      # torch.optim.Adam is re-created on every train() (:310)
         # The reference stacks its shuffled batches ONCE and reuses that list every epoch (:315-325).  The same here: both data
-        # sets are laid out in batch order once (a device gather), so a batch is a contiguous run of rows and the kernels
-        # need no permutation look-up in front of their first load (one dependent memory round trip less per gathering
-        # kernel: the encoder's head, the last layer's targets, the first conv's weight gradient).
-        def frozen(ds, perm):
-            idx = torch.as_tensor(np.asarray(perm, dtype=np.int64), device=ds.device_inputs().device)
-            return ds.device_inputs().index_select(0, idx), ds.device_outputs().index_select(0, idx)
-        eng.set_dataset(_eng.TRAIN, *frozen(train_ds, train_perm))
-        eng.set_dataset(_eng.TEST, *frozen(test_ds, test_perm))
+        # sets are laid out in batch order once - by the normalisation kernel itself, which writes every sample to its row of
+        # the frozen order (DSDataset.device_batches -> cae_normalise_pack_rows) - so a batch is a contiguous run of rows and
+        # the kernels need no permutation look-up in front of their first load (one dependent memory round trip less per
+        # gathering kernel: the encoder's head, the last layer's targets, the first conv's weight gradient).
+        eng.set_dataset(_eng.TRAIN, *train_ds.device_batches(train_perm))
+        eng.set_dataset(_eng.TEST, *test_ds.device_batches(test_perm))
         train_idx = test_idx = None
         par = None
         if dist is not None:

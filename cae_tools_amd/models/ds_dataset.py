@@ -128,12 +128,36 @@ class DSDataset(torch.utils.data.Dataset):
     def device_outputs(self):
         if self._raw_out is None:
             return None
+        if not self.normalise_out:
+            return self._raw_out        # the un-normalised target IS the uploaded variable (one variable, no concat)
         if self._t is None or self._t_norm_flag != self.normalise_out:
             t = torch.empty_like(self._raw_out)
             _eng.normalise_pack(self._raw_out, t, 0, self.min_output, self.max_output, enable=self.normalise_out)
             torch.cuda.synchronize(t.device)
             self._t, self._t_norm_flag = t, self.normalise_out
         return self._t
+
+    def device_batches(self, order):
+        """(x, t) normalised and laid out in the frozen sample order `order` (host sequence of sample indices): row i
+        is sample order[i], so a batch of the frozen shuffle is a contiguous run of rows.  This is the reference's
+        DataLoader(shuffle=True) + default collate, whose stacked batches are built once and reused every epoch
+        (conv_ae_model.py:291-292, 315-325); here the stacking is the normalisation pass itself (cae_normalise_pack_rows
+        writes each sample to its destination row), straight from the raw variables: no second normalised copy."""
+        rows = _eng.inverse_permutation(order, self._raw_in[0].device)
+        x = torch.empty((self.n, self.input_chan, self.input_y, self.input_x), dtype=torch.float32,
+                        device=self._raw_in[0].device)
+        off = 0
+        for name, raw in zip(self.input_variable_names, self._raw_in):
+            _eng.normalise_pack(raw, x, off, self.min_inputs[name], self.max_inputs[name], enable=self.normalise_in,
+                                dst_rows=rows)
+            off += raw.shape[1]
+        t = None
+        if self._raw_out is not None:
+            t = torch.empty_like(self._raw_out)
+            _eng.normalise_pack(self._raw_out, t, 0, self.min_output, self.max_output, enable=self.normalise_out,
+                                dst_rows=rows)
+        torch.cuda.synchronize(x.device)
+        return x, t
 
     def device_mask(self):
         """mask variable as an fp32 CUDA tensor broadcastable to the output, or None (= every pixel)"""

@@ -95,10 +95,19 @@ int cae_set_stream(cae_engine* e, void* hip_stream);
 /* 1: replay each step from a captured hipGraph (default); 0: plain launches */
 int cae_set_graph_mode(cae_engine* e, int enabled);
 
+/* 1: the step functions (cae_train_step(s), cae_eval_step(s), cae_dp_*_steps, cae_forward_backward, cae_adam_step) capture
+ * and cache the hipGraph of the launch sequence they would run and launch NOTHING (no state changes on the device); 0
+ * (default): normal operation.  Lets a host build every graph shape of an epoch loop before its first timed step - the
+ * counterpart of the reference moving its modules to the device before the loop (conv_ae_model.py:312-313).  Without graph
+ * mode the calls are no-ops while it is set. */
+int cae_set_capture_only(cae_engine* e, int enabled);
+
 /* 1 (default): use the specialised kernels where a layer is eligible; 0: shape-generic kernels
  * everywhere (kept as an on-device cross-check of the specialised ones).  Bit 1 (value 3): the backward pass of EVERY
  * eligible channel-rich 3x3 stride-2 decoder layer runs the LDS-staged kernel (kernels_ctbwd.h) instead of the gather
- * pair; with 1 only the layers it is faster on do (one block of 16 input channels: DESIGN.md section 4). */
+ * pair; with 1 only the layers it is faster on do (one block of 16 input channels: DESIGN.md section 4).  Bit 2 (value 5):
+ * the forward pass of those layers runs the gather kernel (k_ig_fwd_s2: what layers with Cin % 4 != 0 or 2-tap kernels
+ * always run) instead of the LDS-staged one - kept selectable so that the full-size parity tests cover it. */
 int cae_set_kernel_mode(cae_engine* e, int specialised);
 
 /* torch.optim.Adam(lr, betas, eps, weight_decay) with L2 decay added to the gradient
@@ -209,6 +218,8 @@ int cae_decode(cae_engine* e, const float* z_dev, int batch, float* y_dev);
 int cae_read_losses(cae_engine* e, int first, int count, double* host_out);
 int cae_loss_slots(const cae_engine* e);
 int cae_sync(cae_engine* e);
+/* Test hook: captured hipGraphs currently cached by the engine (one per distinct launch sequence). */
+int cae_graph_count(const cae_engine* e);
 
 /* Test hook (blocking): copy an internal tensor of the LAST train-mode step to host.
  * what: "act" raw conv output of layer `index` (encoder layers first, then decoder layers except
@@ -244,6 +255,15 @@ int cae_scan_f32(const float* x_dev, int64_t n, void* hip_stream, double* out3_h
  * (0 when range == 0; plain copy when enable == 0).  src (n, c_src, hw), dst (n, c_dst, hw). */
 int cae_normalise_pack(const float* src_dev, int64_t n, int c_src, int64_t hw, float* dst_dev,
                        int c_dst, int c_off, float vmin, float range, int enable, void* hip_stream);
+
+/* conv_ae_model.py:291-292,315-325: DataLoader(shuffle=True) + default collate stack the shuffled samples into batches
+ * ONCE and the list is reused every epoch.  Here the stacking happens in the normalisation pass itself: sample i is
+ * written to row dst_row_dev[i] of dst (the inverse of the frozen sample order, so that a batch is a contiguous run of
+ * rows; NULL = identity, i.e. cae_normalise_pack).  dst_row_dev: n int32 on the device, a permutation of 0..n-1.
+ * cae_invert_permutation builds that table from the frozen order (inverse[perm[i]] = i). */
+int cae_normalise_pack_rows(const float* src_dev, int64_t n, int c_src, int64_t hw, float* dst_dev, int c_dst, int c_off,
+                            float vmin, float range, int enable, const int32_t* dst_row_dev, void* hip_stream);
+int cae_invert_permutation(const int32_t* perm_dev, int64_t n, int32_t* inverse_dev, void* hip_stream);
 
 /* ds_dataset.py:131-135 on base_model.py:123's float64 array: out = vmin + ((double)y * range). */
 int cae_denormalise_f64(const float* y_dev, int64_t n, double vmin, double range, double* out_dev,

@@ -29,28 +29,42 @@ def _setup(n, seed):
     return eng, ref, x, t
 
 
+@pytest.mark.parametrize("mode", [1, 5], ids=["lds-forward", "gather-forward"])
 @pytest.mark.parametrize("batch", [64, 36, 160])
-def test_training_step_at_benchmark_size(batch):
+def test_training_step_at_benchmark_size(batch, mode):
     """64: the benchmark batch (fused encoder+Linear launch, 4 row groups in the fused Linear backward); 36: the reference's
     ragged last batch (a 4-row group); 160: the encoder no longer fits one workgroup's LDS (per-layer launches) and the
-    Linear backward's ten row groups share the eight BatchNorm sum shards"""
+    Linear backward's ten row groups share the eight BatchNorm sum shards.
+    mode 5: the channel-rich decoder layers' forward on the gather kernel k_ig_fwd_s2 (cae_set_kernel_mode bit 2) - the
+    fallback for layers the LDS-staged forward does not take.  Until round 3 its gradients sat 6.8e-4 from the oracle's at
+    batch 64: it folded its BatchNorm sums over lane groups and waves in fp32 (64 values per channel and workgroup) where
+    k_ct_fwd_lds switches to fp64 after a lane's 16 values, and var = E[y^2] - mean^2 amplifies that rounding.
+    Bound: no further from the fp64 oracle than 3x the fp32 oracle itself is (+1e-5 of the tensor's maximum) - a flat
+    fp32-vs-fp32 tolerance flips with the summation order of either side."""
+    from helpers import assert_close_as_reference
+    from oracle import cae_oracle as orc
     torch.set_num_threads(8)
     eng, ref, x, t = _setup(batch, 3)
+    eng.lib.cae_set_kernel_mode(eng.handle, mode)
     slot = eng.forward_backward(0, None, 0, batch, batch)
     loss = eng._read_losses(slot, 1)[0]
     eng.sync()
     loss_ref, _ = ref.loss_and_grads(x, t)
     assert abs(loss - loss_ref) <= 2e-6 * abs(loss_ref)
-    worst = 0.0
+    st = ref.state()
+    side = lambda pre: {k[4:]: (v.double() if v.is_floating_point() else v) for k, v in st.items() if k.startswith(pre)}
+    ref64 = orc.OracleModel(ref.spec, side("enc/"), side("dec/"), lr=1e-3, weight_decay=1e-5)
+    # (the fp32 oracle's forward moved its running statistics; a train-mode forward does not read them)
+    ref64.loss_and_grads(x.double(), t.double())
+    g64 = ref64.grads()
     for k, g in ref.grads().items():
         if "encoder_cnn.0.bias" in k or "encoder_cnn.3.bias" in k or (k.startswith("dec/decoder_conv") and k.endswith("bias") and "15" not in k):
             continue  # biases that feed a BatchNorm: exact-zero gradient here, rounding noise in the reference
-        got = eng.grad_view(k).cpu().numpy()
-        scale = float(g.abs().max())
-        worst = max(worst, float(np.abs(got - g.numpy()).max()) / scale)
-    # fp32 vs fp32, 112,271 parameters, reductions over 4.2 M pixels (10.5 M at batch 160: 4.0e-4 measured, the same with
-    # the fused launches switched off by CAE_HEAD=0 CAE_TAIL=0)
-    assert worst <= (2e-4 if batch <= 64 else 1e-3), worst
+        assert_close_as_reference(eng.grad_view(k).cpu().numpy(), g.numpy(), g64[k].numpy(), f"B={batch} mode={mode} {k}")
+    eng.profile_begin()
+    eng.forward_backward(0, None, 0, batch, batch)
+    labels = {name for (name, layer, us, nbytes) in eng.profile_end()}
+    assert ("ig_convt_fwd" in labels) == (mode == 5) and ("ct_convt_fwd" in labels) == (mode == 1), labels
 
 
 def test_scoring_and_properties_at_benchmark_size():

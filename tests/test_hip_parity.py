@@ -357,6 +357,44 @@ def test_loader_kernels_bit_exact():
     np.testing.assert_array_equal(got, omin + (y32.astype(np.float64) * (omax - omin)))
 
 
+def test_batch_stacking_in_the_normalise_pass_bit_exact():
+    """DataLoader(shuffle=True) + default collate of the reference (conv_ae_model.py:291-292, 315-325) = the normalisation
+    kernel writing sample i to row inverse[i] of the frozen order (cae_normalise_pack_rows + cae_invert_permutation): the
+    rows of DSDataset.device_batches(order) are, bit for bit, the reference DSDataset's normalised samples in that order
+    (tests/golden/ds_dataset.npz), for a multi-variable input (channel offsets) and the single-variable target."""
+    import json, os
+    from helpers import GOLDEN
+    from cae_tools_amd.engine import normalise_pack, inverse_permutation, CaeError
+    from cae_tools_amd.models.ds_dataset import DSDataset
+    from cae_tools_amd.data.arrays import DataArray, Dataset
+    npz = np.load(os.path.join(GOLDEN, "ds_dataset.npz"), allow_pickle=False)
+    meta = json.load(open(os.path.join(GOLDEN, "ds_dataset.json")))
+    names = meta["input_names"]
+    n = npz["lowres"].shape[0]
+    order = np.random.default_rng(4).permutation(n)
+    inv = inverse_permutation(order, torch.device("cuda", torch.cuda.current_device()))
+    assert inv.dtype == torch.int32 and np.array_equal(inv.cpu().numpy()[order], np.arange(n))
+    ds = Dataset()
+    for k in names:
+        ds[k] = DataArray(npz[k], dims=("n", "c_" + k, "y", "x"))
+    ds["hires"] = DataArray(npz["hires"], dims=("n", "c", "Y", "X"))
+    d = DSDataset(ds, names, "hires")
+    assert d.get_normalisation_parameters() == meta["normalisation_parameters"]
+    (x, t) = d.device_batches(order)
+    np.testing.assert_array_equal(x.cpu().numpy(), npz["norm_in"][order])
+    np.testing.assert_array_equal(t.cpu().numpy(), npz["norm_out"][order])
+    # the un-permuted arrays are unchanged by it, and the raw (un-normalised) target is the uploaded variable itself
+    np.testing.assert_array_equal(d.device_inputs().cpu().numpy(), npz["norm_in"])
+    d.set_normalise_output(False)
+    np.testing.assert_array_equal(d.device_outputs().cpu().numpy(), npz["hires"])
+    # a table that is not a permutation is refused on the host
+    with pytest.raises(CaeError):
+        inverse_permutation(np.array([0, 0, 1]), torch.device("cuda"))
+    with pytest.raises(CaeError):
+        normalise_pack(torch.zeros((3, 1, 2, 2), device="cuda"), torch.zeros((3, 1, 2, 2), device="cuda"), 0, 0.0, 1.0,
+                       dst_rows=torch.zeros(2, dtype=torch.int32, device="cuda"))
+
+
 def test_multi_step_graph_equals_single_steps():
     """cae_train_steps / cae_eval_steps (64 steps per captured graph) walk the cursor exactly like 64
     single-step launches: same per-batch losses, same weights afterwards."""

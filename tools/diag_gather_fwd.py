@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Where does the gather forward (k_ig_fwd_s2, cae_set_kernel_mode bit 2) depart from the oracle at the benchmark size?
+Per decoder layer: max |raw conv output - fp64 oracle| (relative to the layer's maximum) for the LDS-staged forward (mode 1),
+the gather forward (mode 5) and the fp32 oracle; then the worst gradient tensor by the flat fp32-vs-fp32 measure VERDICT r2
+quoted (6.8e-4 against a 2e-4 bar) and by the fp64-anchored one.   python tools/diag_gather_fwd.py [batch]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    from test_full_size_gpu import _setup
+    from oracle import cae_oracle as orc
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    torch.set_num_threads(16)
+    eng, ref, x, t = _setup(batch, 3)
+    st = ref.state()
+    side = lambda pre: {k[4:]: (v.double() if v.is_floating_point() else v) for k, v in st.items() if k.startswith(pre)}
+    ref64 = orc.OracleModel(ref.spec, side("enc/"), side("dec/"), lr=1e-3, weight_decay=1e-5)
+    (tr32, tr64) = ({}, {})
+    ref.loss_and_grads(x, t, trace=tr32)
+    ref64.loss_and_grads(x.double(), t.double(), trace=tr64)
+    (g32, g64) = (ref.grads(), ref64.grads())
+    n_enc = len(eng.enc_layers)
+    for mode in (1, 5):
+        eng.lib.cae_set_kernel_mode(eng.handle, mode)
+        slot = eng.forward_backward(0, None, 0, batch, batch)
+        eng._read_losses(slot, 1)
+        eng.sync()
+        print(f"mode {mode}:")
+        for l in range(len(eng.dec_layers) - 1):
+            want = tr64[f"dec_conv{l}"].numpy()
+            got = eng.debug_read("act", n_enc + l, count=want.size).reshape(want.shape).astype(np.float64)
+            o32 = tr32[f"dec_conv{l}"].numpy().astype(np.float64)
+            sc = np.abs(want).max()
+            print(f"  dec conv {l} raw output: hip {np.abs(got - want).max() / sc:.2e}   fp32 oracle {np.abs(o32 - want).max() / sc:.2e}")
+        (worst_flat, worst_anch) = ((0.0, ""), (0.0, ""))
+        for k, g in g32.items():
+            if "encoder_cnn.0.bias" in k or "encoder_cnn.3.bias" in k or (k.startswith("dec/decoder_conv") and k.endswith("bias") and "15" not in k):
+                continue
+            got = eng.grad_view(k).cpu().numpy().astype(np.float64)
+            (a32, a64) = (g.numpy().astype(np.float64), g64[k].numpy())
+            sc = np.abs(a64).max()
+            flat = np.abs(got - a32).max() / np.abs(a32).max()
+            anch = np.abs(got - a64).max() / (3.0 * np.abs(a32 - a64).max() + 1e-5 * sc + 1e-9)
+            if flat > worst_flat[0]:
+                worst_flat = (flat, k)
+            if anch > worst_anch[0]:
+                worst_anch = (anch, k)
+        print(f"  worst gradient, flat fp32-vs-fp32: {worst_flat[0]:.2e} ({worst_flat[1]});  ratio to the fp64-anchored bound: "
+              f"{worst_anch[0]:.2f} ({worst_anch[1]})")
+
+
+if __name__ == "__main__":
+    main()
