@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     from test_full_size_gpu import _setup
     from oracle import cae_oracle as orc
-    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64
     torch.set_num_threads(16)
     eng, ref, x, t = _setup(batch, 3)
     st = ref.state()
@@ -41,6 +41,7 @@ def main():
             sc = np.abs(want).max()
             print(f"  dec conv {l} raw output: hip {np.abs(got - want).max() / sc:.2e}   fp32 oracle {np.abs(o32 - want).max() / sc:.2e}")
         (worst_flat, worst_anch) = ((0.0, ""), (0.0, ""))
+        rows = []
         for k, g in g32.items():
             if "encoder_cnn.0.bias" in k or "encoder_cnn.3.bias" in k or (k.startswith("dec/decoder_conv") and k.endswith("bias") and "15" not in k):
                 continue
@@ -49,10 +50,14 @@ def main():
             sc = np.abs(a64).max()
             flat = np.abs(got - a32).max() / np.abs(a32).max()
             anch = np.abs(got - a64).max() / (3.0 * np.abs(a32 - a64).max() + 1e-5 * sc + 1e-9)
+            rows.append((np.abs(got - a64).max() / sc, np.abs(a32 - a64).max() / sc, k))
             if flat > worst_flat[0]:
                 worst_flat = (flat, k)
             if anch > worst_anch[0]:
                 worst_anch = (anch, k)
+        if "--tensors" in sys.argv:
+            for (eh, er, k) in rows:
+                print(f"    {k:34s} |hip-fp64|/max {eh:.2e}   |fp32 oracle-fp64|/max {er:.2e}   x{eh / max(er, 1e-30):.1f}")
         print(f"  worst gradient, flat fp32-vs-fp32: {worst_flat[0]:.2e} ({worst_flat[1]});  ratio to the fp64-anchored bound: "
               f"{worst_anch[0]:.2f} ({worst_anch[1]})")
 
