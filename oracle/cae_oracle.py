@@ -52,7 +52,23 @@ def layer_table(spec):
     return rows
 
 
-def encoder_forward(spec, enc, x, train, trace=None):
+def _relu(z, name, trace, relu_fix):
+    """F.relu, with two test hooks: the pre-activation is recorded as trace["z:" + name], and relu_fix[name] (a tensor d of
+    z's shape with entries -1 / 0 / +1) overrides the DERIVATIVE at single positions - +1: pass the gradient although z <= 0,
+    -1: block it although z > 0 - without changing the value.  At a large batch some BatchNorm output lies within fp32
+    rounding of zero every few steps, and two correct fp32 implementations then disagree on that one mask bit; a single
+    flipped bit moves every upstream gradient by ~1/sqrt(N) of itself (the sums cancel that far), which says nothing about
+    either implementation.  The parity tests therefore give the oracle the HIP path's decisions at exactly those positions
+    (after checking that its own |z| there is rounding-sized) and compare what is left: tests/helpers.py."""
+    if trace is not None:
+        trace["z:" + name] = z.detach()
+    h = F.relu(z)
+    if relu_fix is not None and name in relu_fix:
+        h = h + relu_fix[name].to(z.dtype) * (z - z.detach())
+    return h
+
+
+def encoder_forward(spec, enc, x, train, trace=None, relu_fix=None):
     """encoder.py:60-64.  `enc` maps reference state_dict keys to tensors; running stats are
     updated in place when train=True (F.batch_norm semantics)."""
     h = x
@@ -65,20 +81,20 @@ def encoder_forward(spec, enc, x, train, trace=None):
                          enc[b + ".bias"], training=train, momentum=BN_MOMENTUM, eps=BN_EPS)
         if train:
             enc[b + ".num_batches_tracked"] += 1
-        h = F.relu(h)
+        h = _relu(h, f"enc_conv{i}", trace, relu_fix)
     h = h.flatten(1)
-    h = F.relu(F.linear(h, enc["encoder_lin.0.weight"], enc["encoder_lin.0.bias"]))
+    h = _relu(F.linear(h, enc["encoder_lin.0.weight"], enc["encoder_lin.0.bias"]), "enc_fc0", trace, relu_fix)
     if trace is not None:
         trace["enc_fc0"] = h.detach()
     z = F.linear(h, enc["encoder_lin.2.weight"], enc["encoder_lin.2.bias"])
     return z
 
 
-def decoder_forward(spec, dec, z, train, trace=None):
+def decoder_forward(spec, dec, z, train, trace=None, relu_fix=None):
     """decoder.py:73-78."""
     layers = spec["output_layers"]
     (c0, y0, x0) = layers[0]["input_dimensions"]
-    h = F.relu(F.linear(z, dec["decoder_lin.0.weight"], dec["decoder_lin.0.bias"]))
+    h = _relu(F.linear(z, dec["decoder_lin.0.weight"], dec["decoder_lin.0.bias"]), "dec_fc0", trace, relu_fix)
     if trace is not None:
         trace["dec_fc0"] = h.detach()
     h = F.linear(h, dec["decoder_lin.2.weight"], dec["decoder_lin.2.bias"])
@@ -96,7 +112,7 @@ def decoder_forward(spec, dec, z, train, trace=None):
                              dec[b + ".bias"], training=train, momentum=BN_MOMENTUM, eps=BN_EPS)
             if train:
                 dec[b + ".num_batches_tracked"] += 1
-            h = F.relu(h)
+            h = _relu(h, f"dec_conv{i}", trace, relu_fix)
     return torch.sigmoid(h)
 
 
@@ -125,11 +141,24 @@ class OracleModel:
             lr=lr, weight_decay=weight_decay)
 
     # -- forward variants ---------------------------------------------------------------
-    def forward(self, x, train, trace=None):
-        z = encoder_forward(self.spec, self.enc, x, train, trace)
+    def forward(self, x, train, trace=None, relu_fix=None):
+        z = encoder_forward(self.spec, self.enc, x, train, trace, relu_fix)
         if trace is not None:
             trace["latent"] = z.detach()
-        return decoder_forward(self.spec, self.dec, z, train, trace)
+        return decoder_forward(self.spec, self.dec, z, train, trace, relu_fix)
+
+    def relu_inputs(self, x):
+        """{name: pre-activation of every ReLU} of a train-mode forward that leaves no trace on the model (running statistics
+        and batch counters put back): what tests/helpers.py compares the HIP path's mask decisions with"""
+        keep = {k: v.clone() for side in (self.enc, self.dec) for k, v in side.items() if not is_param(k)}
+        trace = {}
+        with torch.no_grad():
+            self.forward(x, train=True, trace=trace)
+        for side in (self.enc, self.dec):
+            for k in side:
+                if not is_param(k):
+                    side[k].copy_(keep[k])
+        return {k[2:]: v for k, v in trace.items() if k.startswith("z:")}
 
     def eval_forward(self, x):
         """score(): conv_ae_model.py:223-239 (eval mode, no grad)."""
@@ -142,18 +171,18 @@ class OracleModel:
             return float(F.mse_loss(self.forward(x, train=False), t))
 
     # -- training -----------------------------------------------------------------------
-    def loss_and_grads(self, x, t, trace=None):
+    def loss_and_grads(self, x, t, trace=None, relu_fix=None):
         """forward(train) + MSELoss + backward: conv_ae_model.py:191-196.  Returns the loss and
         leaves .grad on every parameter."""
-        y = self.forward(x, train=True, trace=trace)
+        y = self.forward(x, train=True, trace=trace, relu_fix=relu_fix)
         loss = F.mse_loss(y, t)
         self.optim.zero_grad()
         loss.backward()
         return float(loss.detach()), y.detach()
 
-    def train_step(self, x, t):
+    def train_step(self, x, t, relu_fix=None):
         """one iteration of __train_epoch: conv_ae_model.py:189-200."""
-        loss, _ = self.loss_and_grads(x, t)
+        loss, _ = self.loss_and_grads(x, t, relu_fix=relu_fix)
         self.optim.step()
         return loss
 

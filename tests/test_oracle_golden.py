@@ -92,3 +92,37 @@ def test_loader_arithmetic():
     raw = orc.pack_inputs([npz[n] for n in names], None or [0] * 3, [0] * 3, normalise=False)
     np.testing.assert_array_equal(raw[2], npz["raw_in2"])
     assert np.all(npz["mask"] == 1.0) and npz["mask"].shape == npz["norm_in"].shape
+
+
+def test_relu_decision_hooks_of_the_oracle():
+    """oracle/cae_oracle.py _relu: relu_inputs() leaves no trace on the model; an all-zero relu_fix changes nothing; a +1 / -1
+    entry changes the DERIVATIVE at that position only (the value of the forward pass, hence the loss, stays)."""
+    import torch
+    from helpers import oracle_model
+    case = GoldenCase("cfg2_b4")
+    (x, t) = (torch.from_numpy(case.x), torch.from_numpy(case.t))
+    o = oracle_model(case)
+    before = {k: v.clone() for k, v in o.state().items()}
+    z = o.relu_inputs(x)
+    assert set(z) == {"enc_conv0", "enc_conv1", "enc_fc0", "dec_fc0"} | {f"dec_conv{i}" for i in range(len(case.spec["output_layers"]) - 1)}
+    for k, v in o.state().items():
+        assert torch.equal(v, before[k]), k
+    (loss0, _) = oracle_model(case).loss_and_grads(x, t)
+    a = oracle_model(case)
+    (loss1, _) = a.loss_and_grads(x, t, relu_fix={k: torch.zeros_like(v) for k, v in z.items()})
+    ref = oracle_model(case)
+    ref.loss_and_grads(x, t)
+    assert loss1 == loss0 and all(torch.equal(g, ref.grads()[k]) for k, g in a.grads().items())
+    # block one passing position and pass one blocked position of the first decoder layer
+    zz = z["dec_conv0"]
+    d = torch.zeros_like(zz)
+    pos = tuple(int(i) for i in (zz > 0.1).nonzero()[0])
+    neg = tuple(int(i) for i in (zz < -0.1).nonzero()[0])
+    d[pos] = -1.0
+    d[neg] = 1.0
+    b = oracle_model(case)
+    (loss2, _) = b.loss_and_grads(x, t, relu_fix={"dec_conv0": d})
+    assert loss2 == loss0
+    changed = [k for k, g in b.grads().items() if not torch.equal(g, ref.grads()[k])]
+    assert "dec/decoder_conv.0.weight" in changed and "enc/encoder_cnn.0.weight" in changed
+    assert "dec/decoder_conv.3.weight" not in changed      # downstream of the edited ReLU: untouched
