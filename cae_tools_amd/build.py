@@ -20,10 +20,10 @@ LIB = os.path.join(CSRC, "libcae_hip.so")
 ARCH = "gfx950"
 # source -> headers it includes (csrc/ or include/)
 SOURCES = {
-    "engine.hip": ["kernels_generic.h", "kernels_s2.h", "kernels_last.h", "kernels_rows.h", "kernels_gemm.h", "kernels_igemm.h", "kernels_ctlds.h", "kernels_ctbwd.h", "kernels_head.h", "dp_comm.h", "cae_hip.h"],
+    "engine.hip": ["kernels_generic.h", "kernels_s2.h", "kernels_last.h", "kernels_rows.h", "kernels_gemm.h", "kernels_igemm.h", "kernels_ctlds.h", "kernels_ctbwd.h", "kernels_head.h", "dp_comm.h", "cae_hip.h", "trunk_api.h"],
     "ctbwd.hip": ["kernels_generic.h", "kernels_gemm.h", "kernels_ctbwd.h"],
     "unet_engine.hip": ["kernels_unet.h", "kernels_unet_mfma.h", "cae_unet.h", "cae_hip.h"],
-    "vae_engine.hip": ["kernels_unet.h", "kernels_unet_mfma.h", "kernels_vae.h", "cae_vae.h", "cae_hip.h"],
+    "vae_engine.hip": ["kernels_unet.h", "kernels_vae.h", "cae_vae.h", "cae_hip.h", "trunk_api.h"],
     "linear_engine.hip": ["kernels_unet.h", "kernels_unet_mfma.h", "kernels_vae.h", "cae_linear.h", "cae_hip.h"],
 }
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-cuda-compat", "-Wno-pass-failed"]

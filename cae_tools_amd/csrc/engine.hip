@@ -24,6 +24,7 @@
 #include "kernels_head.h"
 #include "dp_comm.h"
 #include "kernels_ctbwd.h"   // argument struct only: the kernel lives in ctbwd.hip
+#include "trunk_api.h"
 
 // The benchmark geometry's template kernels, instantiated HERE so that their code sits next to the non-template kernels of
 // the same step (implicit instantiations are emitted at the end of the 3 MB text section, 2 MB away): see DESIGN.md §4.
@@ -128,6 +129,11 @@ struct cae_engine {
     bool graph_mode = true;
     bool capture_only = false;   // cae_set_capture_only: step calls capture + cache their graph and launch nothing
     bool use_s2 = true;  // specialised stride-2 kernels (cae_set_kernel_mode)
+    // trunk of the 'var' model (trunk_api.h): fc[1] is the pair of heads [mu | logvar] (2 * latent outputs), z = reparam(heads)
+    // feeds fc[2]; the loss lives outside, so the last decoder layer can hand out its raw output and take its gradient
+    bool variational = false;
+    int64_t off_vz = 0, off_vgz = 0, off_zlast = 0;
+    cae_internal::TrunkHooks hooks{nullptr, nullptr, nullptr};
     bool gather_fwd = false;   // cae_set_kernel_mode bit 2: channel-rich decoder layers' forward on the gather kernel k_ig_fwd_s2
     int ctbwd_mask = 0;  // bit l: decoder layer l's backward runs the LDS-staged kernel (kernels_ctbwd.h) where eligible
     int ctbwd_auto = 0;  // ... the mask chosen at creation (CAE_CTBWD, or the rule in cae_create): its layers have sharded accumulators
@@ -326,6 +332,7 @@ struct StepArgs {
     int cursor_inc = -1;   // samples the cursor moves per step (-1: batch; the global batch under data parallelism)
     // module-level forward (cae_encode / cae_decode): 0 = the whole network, 1 = encoder only (x_direct -> z_out),
     // 2 = decoder only (z_in -> yhat); eval mode, per-layer launches
+    bool external_loss = false;  // trunk mode: the last decoder layer writes its RAW output to off_zlast; its gradient arrives in off_glast
     bool adam_follows = false;   // OP_TRAIN on one device: k_adam is the next launch (it may take the first encoder layer's weight gradient)
     int part = 0;
     const float* z_in = nullptr;
@@ -668,7 +675,7 @@ bool ct_fwd_launch(cae_engine* e, const StepArgs& a, const ConvLayer& L, int lay
 // the batch does not fit (the caller then runs the per-layer launches).
 bool head_plan(const cae_engine* e, const StepArgs& a, HeadArgs& h, size_t& lds_bytes) {
     static const int enabled = env_int("CAE_HEAD", 1);   // env: A/B measurements only
-    if (!enabled || !e->use_s2 || a.syncing() || (int)e->enc.size() > kHeadMaxEnc) return false;
+    if (!enabled || !e->use_s2 || a.syncing() || e->variational || (int)e->enc.size() > kHeadMaxEnc) return false;
     memset(&h, 0, sizeof h);
     h.B = a.batch;
     h.n_enc = (int)e->enc.size();
@@ -799,7 +806,7 @@ bool head_plan(const cae_engine* e, const StepArgs& a, HeadArgs& h, size_t& lds_
 // k_tail_bwd (kernels_head.h): Linear 2..0 backward in one launch.  False: run the per-layer pair launches.
 bool tail_plan(const cae_engine* e, const StepArgs& a, TailArgs& t, size_t& lds_bytes) {
     static const int enabled = env_int("CAE_TAIL", 1);   // env: A/B measurements only
-    if (!enabled || !e->use_s2 || a.syncing()) return false;
+    if (!enabled || !e->use_s2 || a.syncing() || e->variational) return false;
     memset(&t, 0, sizeof t);
     const ConvLayer& P = e->enc.back();
     double* acc = e->gradacc();
@@ -1035,6 +1042,11 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
                                    e->params + F.b_off, F.relu ? 1 : 0, e->fptr(F.act_off));
             }
             in = e->fptr(F.act_off);
+            if (i == 1 && e->variational) {   // heads -> z (trunk_api.h)
+                if (!e->hooks.reparam) return fail(CAE_ERR_STATE, "trunk engine without a reparameterisation hook");
+                e->hooks.reparam(e->hooks.user, s, in, B, e->latent, a.train ? 1 : 0, e->fptr(e->off_vz));
+                in = e->fptr(e->off_vz);
+            }
         }
         if (a.part == 1) {   // the latent vector leaves the engine: (batch, latent) fp32, contiguous like the Linear's output
             HIP_TRY(hipMemcpyAsync(a.z_out, e->fptr(e->fc[1].act_off), sizeof(float) * (size_t)B * e->fc[1].nout, hipMemcpyDeviceToDevice, s));
@@ -1082,7 +1094,10 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
                 ep.target = a.want_loss ? e->ds_t[a.which] : nullptr;
             }
         }
-        if (last && a.train && last_fused_ok(e, L)) continue;   // forward, loss and backward of this layer: one launch, in launch_backward
+        if (last && a.external_loss) {   // raw output for a loss computed outside the trunk: no sigmoid, no statistics
+            ep = epi_plain(e->fptr(e->off_zlast));
+        }
+        if (last && a.train && !a.external_loss && last_fused_ok(e, L)) continue;   // forward, loss and backward of this layer: one launch, in launch_backward
         if (!last && l > 0 && e->dec[l - 1].has_bn && rows_bwd_ok(e, L)) {
             static const int fwd_rows = env_int("CAE_ROWS_FWD", 1);   // env: A/B measurements only
             if (fwd_rows) {
@@ -1113,6 +1128,9 @@ int launch_forward(cae_engine* e, const StepArgs& a) {
                 f.out = ep.out;
                 f.stats = ep.stats;
                 f.epi = a.train ? S2_RAW_STATS : S2_RAW;
+            } else if (a.external_loss) {
+                f.out = ep.out;
+                f.epi = S2_RAW;
             } else {
                 f.out = a.train ? ep.out : ep.yhat;
                 f.target = ep.target;
@@ -1206,7 +1224,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             ain = src_plain(e->fptr(P.act_off), L.cin, L.hin, L.win);
             bna = bn_of(e, P, BN_SAVED, 0, 0);
         }
-        if (last && last_fused_ok(e, L)) {
+        if (last && !a.external_loss && last_fused_ok(e, L)) {
             S2Last f;
             memset(&f, 0, sizeof f);
             f.B = B; f.H = L.hin; f.W = L.win; f.OH = L.hout; f.OW = L.wout;
@@ -1502,7 +1520,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 break;
             }
             const float* gout = e->fptr(F.grad_off);
-            const float* in = i == 0 ? e->fptr(P.act_off) : e->fptr(e->fc[i - 1].act_off);
+            const float* in = i == 0 ? e->fptr(P.act_off) : (i == 2 && e->variational ? e->fptr(e->off_vz) : e->fptr(e->fc[i - 1].act_off));
             BnDesc bni = i == 0 ? bn_of(e, P, BN_SAVED, 0, 0) : bn_none();
             if (e->use_s2) {
                 // weight gradient: dW[o][i] = sum_b gout[b][o] * in[b][i], db[o] = sum_b gout[b][o] (ones column)
@@ -1521,7 +1539,10 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 gd.B = e->params + F.w_off; gd.sb_k = F.nin; gd.sb_n = 1;   // B[k=o][n=i] = W[o][i]
                 gd.sc_m = F.nin; gd.sc_n = 1;
                 size_t lds = gemm_lds(0);
-                if (i > 0) {
+                if (i == 2 && e->variational) {
+                    gd.C = e->fptr(e->off_vgz);   // dL/dz; the hook below turns it into the heads' gradient
+                    gd.epi = GE_STORE;
+                } else if (i > 0) {
                     const FcLayer& G = e->fc[i - 1];
                     gd.C = e->fptr(G.grad_off);
                     gd.epi = G.relu ? GE_RELU_MASK : GE_STORE;
@@ -1559,8 +1580,14 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                 }
                 if (i == 0)
                     if (int rc = sync_bn_table(e, a, P.bn_index)) return rc;
+                if (i == 2 && e->variational) {
+                    if (!e->hooks.reparam_bwd) return fail(CAE_ERR_STATE, "trunk engine without a reparameterisation hook");
+                    e->hooks.reparam_bwd(e->hooks.user, s, e->fptr(e->off_vgz), e->fptr(e->fc[1].act_off), B, e->latent,
+                                         e->fptr(e->fc[1].grad_off));
+                }
                 continue;
             }
+            if (e->variational) return fail(CAE_ERR_STATE, "the trunk mode needs the specialised kernels (cae_set_kernel_mode)");
             {
                 ProfScope _p(e, "linear_wgrad", i, f4((double)B * (F.nin + F.nout)) + 8.0 * F.nin * F.nout);
                 hipLaunchKernelGGL(k_lin_wgrad, dim3(grid1((int64_t)F.nin * F.nout)), dim3(256),
@@ -1592,7 +1619,9 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
         BnDesc bng = bn_of(e, L, BN_BWD, (double)a.bn_batch * L.hout * L.wout, 0);
         Src ain;
         BnDesc bna = bn_none();
-        if (l == 0) {
+        if (l == 0 && a.x_direct) {
+            ain = src_plain(a.x_direct, L.cin, L.hin, L.win);
+        } else if (l == 0) {
             ain = src_plain(e->ds_x[a.which], L.cin, L.hin, L.win);
             ain.perm = a.perm;
             ain.use_cursor = 1;
@@ -1815,14 +1844,23 @@ extern "C" {
 const char* cae_last_error(void) { return g_err.c_str(); }
 int cae_abi_version(void) { return 1; }
 
+static int engine_create_impl(const cae_layer_spec* enc, int n_enc, const cae_layer_spec* dec, int n_dec, int fc_size,
+                              int latent_size, int max_batch, bool variational, cae_engine** out);
+
 int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec* dec, int n_dec, int fc_size,
                       int latent_size, int max_batch, cae_engine** out) {
+    return engine_create_impl(enc, n_enc, dec, n_dec, fc_size, latent_size, max_batch, false, out);
+}
+
+static int engine_create_impl(const cae_layer_spec* enc, int n_enc, const cae_layer_spec* dec, int n_dec, int fc_size,
+                              int latent_size, int max_batch, bool variational, cae_engine** out) {
     if (!enc || !dec || !out || n_enc < 1 || n_dec < 1) return fail(CAE_ERR_ARG, "need >=1 encoder and decoder layer");
     if (fc_size < 1 || latent_size < 1 || max_batch < 1) return fail(CAE_ERR_ARG, "fc/latent/max_batch must be >= 1");
     cae_engine* e = new cae_engine();
     e->fc_size = fc_size;
     e->latent = latent_size;
     e->max_batch = max_batch;
+    e->variational = variational;
     auto bad = [&](const char* msg, int i) {
         delete e;
         return fail(CAE_ERR_ARG, "layer %d: %s", i, msg);
@@ -1879,13 +1917,40 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
     const ConvLayer& EL = e->enc.back();
     const int flat_enc = EL.cout * EL.hout * EL.wout;
     const int flat_dec = dec[0].in_c * dec[0].in_h * dec[0].in_w;
-    const int fdims[4][2] = {{flat_enc, fc_size}, {fc_size, latent_size}, {latent_size, fc_size}, {fc_size, flat_dec}};
+    const int heads = variational ? 2 * latent_size : latent_size;   // trunk mode: [mu | logvar]
+    const int fdims[4][2] = {{flat_enc, fc_size}, {fc_size, heads}, {latent_size, fc_size}, {fc_size, flat_dec}};
     const char* fnames[4] = {"enc/encoder_lin.0", "enc/encoder_lin.2", "dec/decoder_lin.0", "dec/decoder_lin.2"};
     for (int i = 0; i < 4; i++) {
         FcLayer& F = e->fc[i];
         F.nin = fdims[i][0];
         F.nout = fdims[i][1];
         F.relu = (i == 0 || i == 2);
+        if (i == 1 && variational) {
+            // two named tensors per half, ONE (2 * latent, fc) matrix and ONE (2 * latent) bias vector in the arena: the table
+            // lists mu.weight, mu.bias, logvar.weight, logvar.bias (the 'var' model's state_dict order) with those offsets
+            int64_t& top = e->n_param;
+            top = align_up(top, 4);
+            F.w_off = top;
+            top += (int64_t)heads * F.nin;
+            top = align_up(top, 4);
+            F.b_off = top;
+            top += heads;
+            const char* hn[2] = {"enc/encoder_mu", "enc/encoder_logvar"};
+            for (int h = 0; h < 2; h++)
+                for (int part = 0; part < 2; part++) {
+                    cae_tensor_info_t t;
+                    memset(&t, 0, sizeof t);
+                    snprintf(t.name, sizeof t.name, "%s.%s", hn[h], part == 0 ? "weight" : "bias");
+                    t.arena = 0;
+                    t.ndim = part == 0 ? 2 : 1;
+                    t.shape[0] = latent_size;
+                    if (part == 0) t.shape[1] = F.nin;
+                    t.numel = part == 0 ? (int64_t)latent_size * F.nin : latent_size;
+                    t.offset = part == 0 ? F.w_off + (int64_t)h * latent_size * F.nin : F.b_off + (int64_t)h * latent_size;
+                    e->tensors.push_back(t);
+                }
+            continue;
+        }
         add_tensor(e, std::string(fnames[i]) + ".weight", 0, {F.nout, F.nin}, &F.w_off);
         add_tensor(e, std::string(fnames[i]) + ".bias", 0, {F.nout}, &F.b_off);
     }
@@ -1995,6 +2060,11 @@ int cae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
     }
     e->off_glast = carve(top, mb * e->dec.back().out_elems() * 4);
     e->off_xbatch = carve(top, (mb * e->enc[0].in_elems() + e->enc[0].cout) * 4);   // + the layer's gamma before the update
+    if (variational) {
+        e->off_vz = carve(top, mb * latent_size * 4);
+        e->off_vgz = carve(top, mb * latent_size * 4);
+        e->off_zlast = carve(top, mb * e->dec.back().out_elems() * 4);
+    }
     e->ws_need = align_up(top, 256);
     for (auto& L : e->enc)
         if (L.cin > e->max_channels) e->max_channels = L.cin;
@@ -2628,3 +2698,79 @@ int cae_bswap32(void* x, int64_t n, void* hip_stream) {
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// trunk_api.h: the engine as the convolutional trunk of the 'var' model (vae_engine.hip)
+// =================================================================================================
+namespace cae_internal {
+
+int trunk_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec* dec, int n_dec, int fc_size, int latent_size,
+                 int max_batch, cae_engine** out) {
+    return engine_create_impl(enc, n_enc, dec, n_dec, fc_size, latent_size, max_batch, true, out);
+}
+
+void trunk_set_hooks(cae_engine* e, const TrunkHooks& hooks) { e->hooks = hooks; }
+
+float* trunk_raw_output(cae_engine* e) { return e->fptr(e->off_zlast); }
+float* trunk_output_gradient(cae_engine* e) { return e->fptr(e->off_glast); }
+double* trunk_output_bias_acc(cae_engine* e) { return e->gradacc() + e->dec.back().b_off; }
+
+static StepArgs trunk_args(const float* x, int batch, bool train) {
+    StepArgs a{0, nullptr, batch, batch, batch, train, false, x, nullptr, false};
+    return a;
+}
+
+int trunk_forward(cae_engine* e, const float* x, int batch, bool train, bool external_loss, float* yhat) {
+    if (!e || !e->ws || !e->variational) return fail(CAE_ERR_STATE, "trunk_forward: not a bound trunk engine");
+    if (!x || batch < 1 || batch > e->max_batch) return fail(CAE_ERR_ARG, "trunk_forward: batch %d outside [1, %d]", batch, e->max_batch);
+    StepArgs a = trunk_args(x, batch, train);
+    a.external_loss = external_loss;
+    a.yhat = yhat;
+    if (train)   // (see launch_one: every training forward starts from a clean first BatchNorm table; the others are cleared by
+                 // the step tail of the optimiser / gradient hand-over launch)
+        memset(&e->c0_pending, 0, sizeof e->c0_pending);
+    if (int rc = launch_forward(e, a)) return rc;
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int trunk_backward(cae_engine* e, const float* x, int batch) {
+    if (!e || !e->ws || !e->variational) return fail(CAE_ERR_STATE, "trunk_backward: not a bound trunk engine");
+    StepArgs a = trunk_args(x, batch, true);
+    a.external_loss = true;
+    if (int rc = launch_backward(e, a)) return rc;
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int trunk_adam(cae_engine* e) {
+    if (!e || !e->ws) return fail(CAE_ERR_STATE, "trunk_adam: not a bound engine");
+    hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, e->stream, (long long)e->n_param, e->params,
+                       (const float*)nullptr, e->m, e->v, e->hp, (const StepState*)e->state(), e->shard_segs(),
+                       step_tail_of(e, 0, 0), 0, std::log(e->hp.beta1), std::log(e->hp.beta2), AdamConv0{});
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int trunk_gradients(cae_engine* e, float* out, double scale) {
+    if (!e || !e->ws || !out) return fail(CAE_ERR_STATE, "trunk_gradients: bad argument");
+    hipLaunchKernelGGL(k_acc_to_f32, dim3(grid1(e->n_param)), dim3(256), 0, e->stream, (long long)e->n_param, out, e->shard_segs(),
+                       step_tail_of(e, 0, 0));
+    if (scale != 1.0)
+        hipLaunchKernelGGL(k_scale_f32, dim3(grid1(e->n_param)), dim3(256), 0, e->stream, out, (long long)e->n_param, (float)scale);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int trunk_adam_from(cae_engine* e, const float* grads) {
+    if (!e || !e->ws || !grads) return fail(CAE_ERR_STATE, "trunk_adam_from: bad argument");
+    StepTail none;
+    memset(&none, 0, sizeof none);
+    hipLaunchKernelGGL(k_adam, dim3(grid1(e->n_param)), dim3(256), 0, e->stream, (long long)e->n_param, e->params, grads, e->m, e->v,
+                       e->hp, (const StepState*)e->state(), e->shard_segs(), none, 0, std::log(e->hp.beta1), std::log(e->hp.beta2),
+                       AdamConv0{});
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+}  // namespace cae_internal

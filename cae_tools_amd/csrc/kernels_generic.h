@@ -1057,6 +1057,11 @@ __global__ void k_fill_f32(float* __restrict__ p, long long n, float v) {
     if (i < n) p[i] = v;
 }
 
+__global__ void k_scale_f32(float* __restrict__ p, long long n, float f) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] *= f;
+}
+
 __global__ void k_scale_f64(double* __restrict__ p, long long n, double f) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] *= f;

@@ -1,6 +1,6 @@
 // kernels_vae.h — kernels specific to the 'var' (variational autoencoder) path: reparameterisation + KL, and the
 // MS-SSIM loss with its gradient.  The definition is the build's own (oracle/vae_oracle.py: the reference has no source
-// for this path); the convolution / BatchNorm / Linear kernels are those of kernels_unet.h.
+// for this path); the convolutions, BatchNorm, Linear layers and Adam run in the ConvAE engine as a trunk (trunk_api.h).
 //
 // MS-SSIM (Wang et al. 2003, pytorch_msssim conventions): per scale s, with G = 11-tap gaussian (sigma 1.5), valid:
 //   mu_x = G*x, mu_y = G*y, s_xx = G*x^2 - mu_x^2, s_yy = G*y^2 - mu_y^2, s_xy = G*xy - mu_x mu_y
@@ -51,13 +51,17 @@ __device__ __forceinline__ float normal_hash(uint32_t key, uint32_t idx) {
     return (float)(sqrt(-2.0 * log(u1)) * cos(2.0 * 3.14159265358979323846 * u2));
 }
 
+// heads: (B, 2 * L) rows [mu | logvar] - the two heads are ONE Linear layer of the trunk (trunk_api.h).  i = b * L + j is the
+// element's index in the (B, L) latent array (what the noise hash and the oracle count in).
 // z = mu + eps * exp(logvar / 2) (train) or mu (eval); kl_out += -0.5 * sum(1 + lv - mu^2 - exp(lv)).  one block per launch chunk
-__global__ void __launch_bounds__(256) k_reparam(const float* __restrict__ mu, const float* __restrict__ lv, int n, uint32_t key,
-                                                 int train, float* __restrict__ z, float* __restrict__ eps, double* __restrict__ kl_out) {
+__global__ void __launch_bounds__(256) k_reparam(const float* __restrict__ heads, int B, int L, uint32_t key, int train,
+                                                 float* __restrict__ z, float* __restrict__ eps, double* __restrict__ kl_out) {
     __shared__ double red[4];
     double s = 0;
+    const int n = B * L;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float m = mu[i], l = lv[i];
+        const int b = i / L, j = i - b * L;
+        const float m = heads[(size_t)b * 2 * L + j], l = heads[(size_t)b * 2 * L + L + j];
         float e = 0.f;
         if (train) e = normal_hash(key, (uint32_t)i);
         eps[i] = e;
@@ -68,15 +72,18 @@ __global__ void __launch_bounds__(256) k_reparam(const float* __restrict__ mu, c
     if (threadIdx.x == 0) atomicAdd(kl_out, -0.5 * t);
 }
 
-// dmu = dz + lambda_kl * mu / n;  dlv = dz * eps * 0.5 * exp(lv/2) + lambda_kl * 0.5 * (exp(lv) - 1) / n
-__global__ void __launch_bounds__(256) k_reparam_bwd(const float* __restrict__ dz, const float* __restrict__ mu,
-                                                     const float* __restrict__ lv, const float* __restrict__ eps, int n,
-                                                     float lambda_kl, float* __restrict__ dmu, float* __restrict__ dlv) {
+// dmu = dz + lambda_kl * mu / n;  dlv = dz * eps * 0.5 * exp(lv/2) + lambda_kl * 0.5 * (exp(lv) - 1) / n;  rows [dmu | dlv]
+__global__ void __launch_bounds__(256) k_reparam_bwd(const float* __restrict__ dz, const float* __restrict__ heads,
+                                                     const float* __restrict__ eps, int B, int L, float lambda_kl,
+                                                     float* __restrict__ dheads) {
+    const int n = B * L;
     const float k = lambda_kl / (float)n;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float l = lv[i];
-        dmu[i] = dz[i] + k * mu[i];
-        dlv[i] = dz[i] * eps[i] * 0.5f * expf(0.5f * l) + k * 0.5f * (expf(l) - 1.f);
+        const int b = i / L, j = i - b * L;
+        const size_t o = (size_t)b * 2 * L + j;
+        const float m = heads[o], l = heads[o + L];
+        dheads[o] = dz[i] + k * m;
+        dheads[o + L] = dz[i] * eps[i] * 0.5f * expf(0.5f * l) + k * 0.5f * (expf(l) - 1.f);
     }
 }
 
@@ -262,9 +269,10 @@ __global__ void __launch_bounds__(256) k_sigmoid_gather(const float* __restrict_
     }
 }
 
-// du = (lambda_mse * 2 (y - t) / n + gssim) * y (1 - y);  mse_out += sum (y-t)^2 / n
+// du = scale * (lambda_mse * 2 (y - t) / n + gssim) * y (1 - y);  mse_out += sum (y-t)^2 / n
+// (scale: the data-parallel weight local / global batch of this rank's gradient, 1 on a single device)
 __global__ void __launch_bounds__(256) k_vae_loss_grad(const float* __restrict__ y, const float* __restrict__ t,
-                                                       const float* __restrict__ gssim, long long n, float lambda_mse,
+                                                       const float* __restrict__ gssim, long long n, float lambda_mse, float scale,
                                                        float* __restrict__ du, double* __restrict__ mse_out) {
     __shared__ double red[4];
     double s = 0;
@@ -272,7 +280,7 @@ __global__ void __launch_bounds__(256) k_vae_loss_grad(const float* __restrict__
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float yv = y[i], d = yv - t[i];
         s += (double)d * (double)d;
-        if (du) du[i] = (k * d + (gssim ? gssim[i] : 0.f)) * yv * (1.f - yv);
+        if (du) du[i] = scale * ((k * d + (gssim ? gssim[i] : 0.f)) * yv * (1.f - yv));
     }
     const double tt = block_sum(s, red);
     if (threadIdx.x == 0) atomicAdd(mse_out, tt / (double)n);
