@@ -257,7 +257,7 @@ Epi epi_plain(float* out) {
 size_t lds_bytes(int c1, int c2) { return 4 * sizeof(double) + (size_t)(c1 + c2 + 1) * sizeof(float4); }
 
 int grid1(int64_t n) { return (int)((n + 255) / 256); }
-size_t gemm_lds(int channels) { return (4 * 256 + 128) * sizeof(float) + (size_t)(channels + 1) * sizeof(float4); }
+size_t gemm_lds(int channels) { return (4 * 256 + 256) * sizeof(float) + (size_t)(channels + 1) * sizeof(float4); }
 
 // positions per block for k_wgrad: aim for ~2048 blocks in total, at least 256 positions each
 int wgrad_ppb(int64_t positions, int64_t nweights) {
@@ -1380,7 +1380,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
                             c.bands = bands;
                             c.hb = hb;
                             parts = bands;
-                            lds_launch = (32 + 4 * (size_t)(L.cin + L.cout) + (size_t)L.cout * gstr + 4 + 16 * (size_t)astr + 4 +
+                            lds_launch = (32 * (size_t)kCtbWaves + 4 * (size_t)(L.cin + L.cout) + (size_t)L.cout * gstr + 4 + 16 * (size_t)astr + 4 +
                                           16 * (size_t)wstr + 3 * (size_t)astr + (size_t)kCtbWaves * 16 * 17 + 8) * sizeof(float);
                         }
                     }
@@ -1435,7 +1435,7 @@ int launch_backward(cae_engine* e, const StepArgs& a) {
             fd.tiles_per_wave = tpw_env > 0 ? tpw_env : (mtiles >= 8192 ? 2 : 1);
             const int per_block = (4 / fd.ksplit) * fd.tiles_per_wave;
             const int d_gx = (mtiles + per_block - 1) / per_block, d_gy = (L.cin + 15) / 16;
-            const size_t lds_d = (32 + 1024) * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4) +
+            const size_t lds_d = (128 + 1024) * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4) +
                                  (size_t)L.cout * L.kh * L.kw * 2 * sizeof(int);
             const size_t lds_w = 1024 * sizeof(float) + (size_t)(L.cin + L.cout + 1) * sizeof(float4);
             ProfScope _p(e, "ig_convt_bwd_pair", l,

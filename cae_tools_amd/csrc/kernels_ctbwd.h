@@ -49,7 +49,7 @@ constexpr int kCtbW4 = 3;      // ... of the weight rows
 constexpr int kCtbKChunk = 64; // positions per weight-gradient task (16 k-steps)
 
 inline size_t ct_bwd_lds_bytes(int Cin, int Cout, int imgs, int HW, int OHW, int wstr) {
-    size_t floats = 32;                                   // producer sums
+    size_t floats = 32 * (size_t)kCtbWaves;               // producer sums, per wave
     floats += 4 * (size_t)(Cin + Cout);                   // BatchNorm constants
     floats += (size_t)imgs * Cout * OHW;                  // gradient maps (a multiple of 4 floats: Cout % 4 == 0)
     floats += (size_t)imgs * 16 * HW;                     // producer outputs of the channel block
@@ -67,8 +67,8 @@ inline size_t ct_bwd_lds_bytes(int Cin, int Cout, int imgs, int HW, int OHW, int
 template <bool BAND>
 __device__ __forceinline__ void ct_bwd_body(const CtBwd& a) {
     extern __shared__ double lds_d[];
-    float* lstat = reinterpret_cast<float*>(lds_d);                     // [16][2]
-    float4* cout4 = reinterpret_cast<float4*>(lstat + 32);              // [Cout]
+    float* lstat = reinterpret_cast<float*>(lds_d);                     // [waves][16][2]: one writer per slot, folded in wave order
+    float4* cout4 = reinterpret_cast<float4*>(lstat + 32 * kCtbWaves);  // [Cout]
     float4* cin4 = cout4 + a.Cout;                                      // [Cin]
     const int HW = a.H * a.W, OHW = a.OH * a.OW, KK = 9, N = a.Cout * KK;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -170,7 +170,7 @@ __device__ __forceinline__ void ct_bwd_body(const CtBwd& a) {
             a.bg.gamma_acc[c] = sg * a.bg.scale;
         }
     }
-    if (tid < 32) lstat[tid] = 0.f;
+    if (tid < 32 * kCtbWaves) lstat[tid] = 0.f;
     // the producer outputs, the weights and the position tables do not need the constants
 #pragma unroll
     for (int u = 0; u < NA; u++) {
@@ -358,7 +358,7 @@ __device__ __forceinline__ void ct_bwd_body(const CtBwd& a) {
             // register j of lane (r, q) is row (channel) 4q + j, column n
             if (n_ok) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) atomicAdd(&wacc_sh[(size_t)(cb * 16 + 4 * q + j) * N + n], (double)(acc[j] + acc1[j]));
+                for (int j = 0; j < 4; j++) acc_add<ACC_GRAD>(&wacc_sh[(size_t)(cb * 16 + 4 * q + j) * N + n], (double)(acc[j] + acc1[j]));
             }
         }
     }
@@ -373,16 +373,19 @@ __device__ __forceinline__ void ct_bwd_body(const CtBwd& a) {
             t1 += dpp_f<0x4E>(t1);  t2 += dpp_f<0x4E>(t2);
             t1 += dpp_f<0x141>(t1); t2 += dpp_f<0x141>(t2);
             t1 += dpp_f<0x140>(t1); t2 += dpp_f<0x140>(t2);
-            if (pl == 0) {
-                atomicAdd(&lstat[2 * (4 * cg + cc)], t1);
-                atomicAdd(&lstat[2 * (4 * cg + cc) + 1], t2);
+            if (pl == 0) {   // the only lane of this wave with channel (cg, cc): a plain store, no atomics
+                lstat[wv * 32 + 2 * (4 * cg + cc)] = t1;
+                lstat[wv * 32 + 2 * (4 * cg + cc) + 1] = t2;
             }
         }
         __syncthreads();
         if (tid < 32) {
             const int c = cb * 16 + (tid >> 1);
             const int shard = (blockIdx.x + blockIdx.y + blockIdx.z) & (kStatShards - 1);
-            atomicAdd(&a.stats_prev[((size_t)shard * a.Cin + c) * 4 + 2 + (tid & 1)], (double)lstat[tid]);
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < kCtbWaves; w++) t += (double)lstat[w * 32 + tid];
+            acc_add<ACC_GRAD>(&a.stats_prev[((size_t)shard * a.Cin + c) * 4 + 2 + (tid & 1)], t);
         }
     }
     CTB_STAMP(5);

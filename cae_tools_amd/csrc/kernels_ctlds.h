@@ -303,15 +303,15 @@ __global__ void __launch_bounds__(512) k_ct_fwd_lds(CtFwd a) {
         d1 += __shfl_xor(d1, 16, 64); d2 += __shfl_xor(d2, 16, 64);
         d1 += __shfl_xor(d1, 32, 64); d2 += __shfl_xor(d2, 32, 64);
         if (q == 0 && col_ok) {
-            atomicAdd(&lstat[2 * r], d1);
-            atomicAdd(&lstat[2 * r + 1], d2);
+            atomicAdd(&lstat[2 * r], acc_grid<ACC_STAT>(d1));       // (on the grid: exact, hence order-independent, adds)
+            atomicAdd(&lstat[2 * r + 1], acc_grid<ACC_STAT>(d2));
         }
         __syncthreads();
         if (tid < 32) {
             const int c = cb * 16 + (tid >> 1);
             if (c < a.Cout) {
                 const int shard = (blockIdx.x + blockIdx.y) & (kStatShards - 1);
-                atomicAdd(&a.stats[((size_t)shard * a.Cout + c) * 4 + (tid & 1)], lstat[tid]);
+                acc_add<ACC_STAT>(&a.stats[((size_t)shard * a.Cout + c) * 4 + (tid & 1)], lstat[tid]);
             }
         }
     }

@@ -47,12 +47,12 @@ struct GemmArgs {
 // every k-chain short.  Loads are issued 8 k-steps at a time ahead of their MFMAs.
 __device__ __forceinline__ void gemm16_body(const GemmArgs& g, const int bx, double* lds_d) {
     float* part = reinterpret_cast<float*>(lds_d);              // [4 waves][256] partial tiles
-    float* lstat = part + 4 * 256;                              // [<=64 channels][2] GE_BN_MASK sums
-    float4* ca = reinterpret_cast<float4*>(lstat + 128);
+    double* lstat = reinterpret_cast<double*>(part + 4 * 256);  // [<=64 channels][2] GE_BN_MASK sums: fp64 on the accumulation grid
+    float4* ca = reinterpret_cast<float4*>(part + 4 * 256 + 256);
     float4* cc = ca + (g.bn_a.mode ? g.bn_a.C : 0);
     bn_consts(g.bn_a, ca, bx == 0);
     bn_consts(g.bn_c, cc, false, 64);
-    if (threadIdx.x < 128) lstat[threadIdx.x] = 0.f;
+    if (threadIdx.x < 128) lstat[threadIdx.x] = 0.0;
     __syncthreads();
 
     const int tiles_n = (g.N + 15) >> 4;
@@ -123,8 +123,10 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g, const int bx, dou
                 const float d = g.H[off] - c4.x;
                 const float gm = fmaf(d, c4.y, c4.z) > 0.f ? v : 0.f;
                 g.C[off] = gm;
-                atomicAdd(&lstat[2 * ch], gm);              // LDS atomics: a tile spans <= 16 channels
-                atomicAdd(&lstat[2 * ch + 1], gm * (d * c4.w));
+                // LDS atomics (a tile spans <= 16 channels), many lanes per slot: addends on the accumulation grid, so that the
+                // adds are exact and their order does not matter
+                atomicAdd(&lstat[2 * ch], acc_grid<ACC_GRAD>((double)gm));
+                atomicAdd(&lstat[2 * ch + 1], acc_grid<ACC_GRAD>((double)(gm * (d * c4.w))));
             } else if (g.epi == GE_ACC64_T) {
                 if (g.ones_row && cm == g.M - 1) {
                     g.accB[cn] = (double)v;
@@ -146,8 +148,8 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& g, const int bx, dou
         const int i = threadIdx.x;
         if (i < 2 * (c1 - c0 + 1)) {
             const int ch = c0 + (i >> 1);
-            atomicAdd(&g.stats_c[((size_t)(bx & (kStatShards - 1)) * g.bn_c.C + ch) * 4 + 2 + (i & 1)],
-                      (double)lstat[2 * ch + (i & 1)]);
+            acc_add<ACC_GRAD>(&g.stats_c[((size_t)(bx & (kStatShards - 1)) * g.bn_c.C + ch) * 4 + 2 + (i & 1)],
+                      lstat[2 * ch + (i & 1)]);
         }
     }
 }

@@ -23,6 +23,32 @@ namespace cae {
 // consumers add the copies up in bn_consts.
 constexpr int kStatShards = 8;
 
+// ---- order-independent accumulation -----------------------------------------------------------------------------------------
+// Every sum over workgroups (and the few over waves that go through LDS atomics) is a set of fp64 atomic adds whose ORDER
+// differs from run to run.  fp64 addition is not associative, so such a sum is reproducible to ~1e-16 but not bitwise - and
+// one last bit of an fp64 sum is, every few thousand values, one last bit of the fp32 number derived from it.  Here every
+// addend is first rounded to a fixed absolute grid q (a power of two per kind of quantity).  A sum of multiples of q is EXACT
+// in fp64 as long as it stays below 2^53 q, exact addition is associative, and the result therefore does not depend on the
+// order the atomics arrive in: the training step is bitwise reproducible from run to run (tests/test_reproducible_gpu.py),
+// for two fp64 instructions per atomic.  The grids:
+//   ACC_STAT  sum y, sum y^2 of a BatchNorm layer (table slots 0, 1): q = 2^-28 (3.7e-9), exact while |sum| < 2^25 = 3.4e7
+//             (N E[y^2] of a layer: 2e6 values of order 1 at the benchmark size);
+//   ACC_GRAD  everything gradient-sized - sum g and sum g x_hat of BatchNorm backward (slots 2, 3), weight and bias gradients,
+//             the loss: q = 2^-50 (8.9e-16), exact while |sum| < 8.
+// A sum that leaves its window is not wrong, it merely rounds as fp64 sums always did (reproducible to ~1e-16 again); the
+// resolution costs at most 0.5 q per addend (a few thousand addends per sum: 1e-12 relative on the statistics of the
+// smallest layer, 1e-9 on a gradient element of 1e-6).
+enum AccKind : int { ACC_STAT = 0, ACC_GRAD = 1 };
+template <int KIND>
+__device__ __forceinline__ double acc_grid(double v) {
+    constexpr double S = KIND == ACC_STAT ? 268435456.0 : 1125899906842624.0;   // 2^28, 2^50
+    return __dmul_rn(rint(__dmul_rn(v, S)), 1.0 / S);
+}
+template <int KIND>
+__device__ __forceinline__ void acc_add(double* p, double v) {
+    atomicAdd(p, acc_grid<KIND>(v));
+}
+
 // Gradient accumulators that many workgroups hit at once (weights of the thin stride-2 layers,
 // the last layer's bias) live in a sharded side table [kStatShards][n]; Adam adds the shards up.
 struct ShardSeg {
@@ -356,16 +382,16 @@ __device__ __forceinline__ void epi_block(const Epi& e, int c, const StepState* 
     if (threadIdx.x == 0) {
         const size_t row = ((size_t)(bx & (kStatShards - 1)) * e.stats_C + c) * 4;
         if (e.kind == EPI_STATS) {
-            atomicAdd(&e.stats[row + 0], t1);
-            atomicAdd(&e.stats[row + 1], t2);
+            acc_add<ACC_STAT>(&e.stats[row + 0], t1);
+            acc_add<ACC_STAT>(&e.stats[row + 1], t2);
         } else if (e.kind == EPI_MASKSTATS) {
-            atomicAdd(&e.stats[row + 2], t1);
-            atomicAdd(&e.stats[row + 3], t2);
+            acc_add<ACC_GRAD>(&e.stats[row + 2], t1);
+            acc_add<ACC_GRAD>(&e.stats[row + 3], t2);
         } else if (e.kind == EPI_SIGMSE) {
-            atomicAdd(&e.losses[(size_t)st->loss_slot * kStatShards + (bx & (kStatShards - 1))], t1);
-            atomicAdd(&e.bias_acc[c], t2);
+            acc_add<ACC_GRAD>(&e.losses[(size_t)st->loss_slot * kStatShards + (bx & (kStatShards - 1))], t1);
+            acc_add<ACC_GRAD>(&e.bias_acc[c], t2);
         } else {
-            atomicAdd(&e.losses[(size_t)st->loss_slot * kStatShards + (bx & (kStatShards - 1))], t1);
+            acc_add<ACC_GRAD>(&e.losses[(size_t)st->loss_slot * kStatShards + (bx & (kStatShards - 1))], t1);
         }
     }
 }
@@ -643,7 +669,7 @@ __device__ __forceinline__ void wgrad_body(const ConvGeom& g, const Src& small, 
         sum = fmaf(bn_apply(bns.mode, ks, sp, sq), bn_apply(bnb.mode, kb, lp, lq), sum);
     }
     const double t = block_sum((double)sum, red);
-    if (threadIdx.x == 0) atomicAdd(&acc[bx], t);
+    if (threadIdx.x == 0) acc_add<ACC_GRAD>(&acc[bx], t);
 }
 
 __global__ void __launch_bounds__(256) k_wgrad(ConvGeom g, Src small, BnDesc bns, Src big, BnDesc bnb,
@@ -762,8 +788,8 @@ __global__ void __launch_bounds__(256) k_lin_dgrad(int B, int nin, int nout, con
     const double t2 = block_sum(r2, red);
     if (threadIdx.x == 0) {
         const size_t row = ((size_t)(blockIdx.x & (kStatShards - 1)) * bne.C + c) * 4;
-        atomicAdd(&stats[row + 2], t1);
-        atomicAdd(&stats[row + 3], t2);
+        acc_add<ACC_GRAD>(&stats[row + 2], t1);
+        acc_add<ACC_GRAD>(&stats[row + 3], t2);
     }
 }
 

@@ -692,8 +692,8 @@ __device__ __forceinline__ void tail_wgrad(const float* g, int ldg, int nin, int
                              [=](int m, int k) { return g[k * ldg + m]; },
                              [=](int k, int n) { return n == nin ? 1.0f : in(k, n); },
                              [=](int m, int n, float v) {
-                                 if (n == nin) atomicAdd(&accB[m], (double)v);
-                                 else atomicAdd(&accW[(size_t)m * nin + n], (double)v);
+                                 if (n == nin) acc_add<ACC_GRAD>(&accB[m], (double)v);
+                                 else acc_add<ACC_GRAD>(&accW[(size_t)m * nin + n], (double)v);
                              });
 }
 
@@ -826,8 +826,8 @@ __global__ void __launch_bounds__(kHeadThreads) k_tail_bwd(TailArgs a) {
                     row[2] = t1;
                     row[3] = t2;
                 } else {
-                    atomicAdd(&row[2], t1);
-                    atomicAdd(&row[3], t2);
+                    acc_add<ACC_GRAD>(&row[2], t1);
+                    acc_add<ACC_GRAD>(&row[3], t2);
                 }
             }
             __syncthreads();

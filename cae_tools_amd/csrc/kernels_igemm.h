@@ -216,15 +216,15 @@ __global__ void __launch_bounds__(256) k_ig_fwd_s2(IgFwd a) {
         d1 += __shfl_xor(d1, 16, 64); d2 += __shfl_xor(d2, 16, 64);
         d1 += __shfl_xor(d1, 32, 64); d2 += __shfl_xor(d2, 32, 64);
         if (q == 0 && co < a.Cout) {
-            atomicAdd(&lstat[2 * r], d1);
-            atomicAdd(&lstat[2 * r + 1], d2);
+            atomicAdd(&lstat[2 * r], acc_grid<ACC_STAT>(d1));       // (on the grid: exact, hence order-independent, adds)
+            atomicAdd(&lstat[2 * r + 1], acc_grid<ACC_STAT>(d2));
         }
         __syncthreads();
         if (threadIdx.x < 32) {
             const int c = blockIdx.z * 16 + (threadIdx.x >> 1);
             if (c < a.Cout) {
                 const int shard = (blockIdx.x + blockIdx.y) & (kStatShards - 1);
-                atomicAdd(&a.stats[((size_t)shard * a.Cout + c) * 4 + (threadIdx.x & 1)], lstat[threadIdx.x]);
+                acc_add<ACC_STAT>(&a.stats[((size_t)shard * a.Cout + c) * 4 + (threadIdx.x & 1)], lstat[threadIdx.x]);
             }
         }
         IG_STAMP(4);
@@ -254,8 +254,8 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
 #define IGD_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && by == 0 && bx < 256) a.dbg[(512 + bx) * 4 + (i)] = wall_clock64(); } while (0)
     IGD_STAMP(0);
     const int K = a.Cout * a.KH * a.KW;
-    float* lstat = reinterpret_cast<float*>(lds_d);               // [16][2]
-    float* part = lstat + 32;                                     // [4][256] split-K partial tiles
+    float* lstat = reinterpret_cast<float*>(lds_d);               // [4 waves][16][2]: one writer per slot, folded in wave order
+    float* part = lstat + 128;                                    // [4][256] split-K partial tiles
     float4* cout4 = reinterpret_cast<float4*>(part + 1024);       // [Cout]
     float4* cprev4 = cout4 + a.Cout;                              // [Cin]
     int2* koff = reinterpret_cast<int2*>(cprev4 + a.Cin);         // [K] {offset of tap k inside one image of gy, its channel}
@@ -266,7 +266,7 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
         const int ky = t / a.KW, kx = t - ky * a.KW;
         koff[k] = make_int2((co * a.OH + ky) * a.OW + kx, co);
     }
-    if (threadIdx.x < 32) lstat[threadIdx.x] = 0.f;
+    if (threadIdx.x < 128) lstat[threadIdx.x] = 0.f;
     __syncthreads();
     IGD_STAMP(1);
 
@@ -415,9 +415,9 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
                     e1 += dpp_f<0x4E>(e1); e2 += dpp_f<0x4E>(e2);
                     e1 += dpp_f<0x141>(e1); e2 += dpp_f<0x141>(e2);
                     e1 += dpp_f<0x140>(e1); e2 += dpp_f<0x140>(e2);
-                    if (r == 15 && cc < a.Cin) {
-                        atomicAdd(&lstat[2 * (q * 4 + jj)], e1);
-                        atomicAdd(&lstat[2 * (q * 4 + jj) + 1], e2);
+                    if (r == 15 && cc < a.Cin) {   // the only lane of this wave that owns slot (q, jj): no atomics, a fixed order
+                        lstat[wv * 32 + 2 * (q * 4 + jj)] += e1;
+                        lstat[wv * 32 + 2 * (q * 4 + jj) + 1] += e2;
                     }
                 }
             }
@@ -429,7 +429,9 @@ __device__ __forceinline__ void ig_dgrad_body(const IgDgrad& a, const int bx, co
             const int c = by * 16 + (threadIdx.x >> 1);
             if (c < a.Cin) {
                 const int shard = bx & (kStatShards - 1);
-                atomicAdd(&a.stats_prev[((size_t)shard * a.Cin + c) * 4 + 2 + (threadIdx.x & 1)], (double)lstat[threadIdx.x]);
+                const double t = (double)lstat[threadIdx.x] + (double)lstat[32 + threadIdx.x] + (double)lstat[64 + threadIdx.x] +
+                                 (double)lstat[96 + threadIdx.x];
+                acc_add<ACC_GRAD>(&a.stats_prev[((size_t)shard * a.Cin + c) * 4 + 2 + (threadIdx.x & 1)], t);
             }
         }
     }
@@ -552,7 +554,7 @@ __device__ __forceinline__ void ig_wgrad_body(const IgWgrad& a, const int bx, co
         const int cm = tm * 16 + q * 4 + j;
         if (cm >= a.Cin) continue;
         const float v = part[j * 64 + lane] + part[256 + j * 64 + lane] + part[512 + j * 64 + lane] + part[768 + j * 64 + lane];
-        atomicAdd(&a.wacc[(size_t)cm * N + cn], (double)v);
+        acc_add<ACC_GRAD>(&a.wacc[(size_t)cm * N + cn], (double)v);
     }
     IGW_STAMP(3);
 }

@@ -521,18 +521,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
         if (j < NRED) {
             const double s = (double)redf[j] + (double)redf[NRED + j] + (double)redf[2 * NRED + j] + (double)redf[3 * NRED + j];
             if (j < NACC) {
-                atomicAdd(&a.wacc[(size_t)shard * a.acc_stride + j], s);
+                acc_add<ACC_GRAD>(&a.wacc[(size_t)shard * a.acc_stride + j], s);
             } else if (a.stats_in) {
                 const int jj = j - NACC;
-                atomicAdd(&a.stats_in[((size_t)shard * CIN + (jj >> 1)) * 4 + 2 + (jj & 1)], s);
+                acc_add<ACC_GRAD>(&a.stats_in[((size_t)shard * CIN + (jj >> 1)) * 4 + 2 + (jj & 1)], s);
             }
         } else {
             const int q = j - NRED, co = q >> 1, which = q & 1;
             double s = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; w++) s += redd[(w * COUT + co) * 2 + which];
-            if (which == 0) atomicAdd(&a.losses[(size_t)loss_slot_v * kStatShards + shard], s);
-            else atomicAdd(&a.bias_acc[(size_t)shard * a.acc_stride + co], s);
+            if (which == 0) acc_add<ACC_GRAD>(&a.losses[(size_t)loss_slot_v * kStatShards + shard], s);
+            else acc_add<ACC_GRAD>(&a.bias_acc[(size_t)shard * a.acc_stride + co], s);
         }
     }
     LF_STAMP(5);

@@ -348,10 +348,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 #pragma unroll
         for (int q = 0; q < NB; q++) s += (double)redf[(q * CS + gsel) * NRED + j];
         if (j < NACC) {
-            atomicAdd(&a.wacc[(size_t)shard * a.wacc_stride + (size_t)gsel * NACC + j], s);
+            acc_add<ACC_GRAD>(&a.wacc[(size_t)shard * a.wacc_stride + (size_t)gsel * NACC + j], s);
         } else {
             const int jj = j - NACC;
-            atomicAdd(&a.stats_in[((size_t)shard * CIN + gsel * CT + (jj >> 1)) * 4 + 2 + (jj & 1)], s);
+            acc_add<ACC_GRAD>(&a.stats_in[((size_t)shard * CIN + gsel * CT + (jj >> 1)) * 4 + 2 + (jj & 1)], s);
         }
     }
     RW_STAMP(5);
@@ -570,7 +570,7 @@ __global__ void __launch_bounds__(256) k_s2_fwd_rows(S2FwdRows a) {
     __syncthreads();
     if (tid < NRED) {
         const double s = (double)redf[tid] + (double)redf[NRED + tid] + (double)redf[2 * NRED + tid] + (double)redf[3 * NRED + tid];
-        atomicAdd(&a.stats[((size_t)(blockIdx.x & (kStatShards - 1)) * COUT + (tid >> 1)) * 4 + (tid & 1)], s);
+        acc_add<ACC_STAT>(&a.stats[((size_t)(blockIdx.x & (kStatShards - 1)) * COUT + (tid >> 1)) * 4 + (tid & 1)], s);
     }
 }
 

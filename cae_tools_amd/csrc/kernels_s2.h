@@ -258,13 +258,13 @@ __global__ void __launch_bounds__(256) k_s2_fwd(S2Fwd a) {
             const double s = red[i] + red[2 * COUT + i] + red[4 * COUT + i] + red[6 * COUT + i];
             const int co = i >> 1;
             if (EPI == S2_RAW_STATS) {
-                atomicAdd(&a.stats[((size_t)(blockIdx.x & (kStatShards - 1)) * COUT + co) * 4 + (i & 1)], s);
+                acc_add<ACC_STAT>(&a.stats[((size_t)(blockIdx.x & (kStatShards - 1)) * COUT + co) * 4 + (i & 1)], s);
             } else {
                 const int shard = blockIdx.x & (kStatShards - 1);
                 if ((i & 1) == 0) {
-                    atomicAdd(&a.losses[(size_t)a.st->loss_slot * kStatShards + shard], s);
+                    acc_add<ACC_GRAD>(&a.losses[(size_t)a.st->loss_slot * kStatShards + shard], s);
                 } else if (EPI == S2_SIGMSE) {
-                    atomicAdd(&a.bias_acc[(size_t)shard * a.bias_stride + co], s);
+                    acc_add<ACC_GRAD>(&a.bias_acc[(size_t)shard * a.bias_stride + co], s);
                 }
             }
         }
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) k_s2_fwd_cs(S2Fwd a) {
         double sum = 0.0;
 #pragma unroll
         for (int w = 0; w < WPG; w++) sum += red[(c * WPG + w) * 2 + i];
-        atomicAdd(&a.stats[((size_t)(blockIdx.x & (kStatShards - 1)) * COUT + c) * 4 + i], sum);
+        acc_add<ACC_STAT>(&a.stats[((size_t)(blockIdx.x & (kStatShards - 1)) * COUT + c) * 4 + i], sum);
     }
 }
 
@@ -554,11 +554,11 @@ __global__ void __launch_bounds__(256) k_s2_bwd(S2Bwd a) {
             // j = ((c*COUT + co)*KH + ky)*KW + kx  ->  global weight index with ci = gsel*CT + c
             const int c = j / (COUT * KH * KW), rest = j - c * (COUT * KH * KW);
             const int ci = gsel * CT + c;
-            atomicAdd(&a.wacc[(size_t)(blockIdx.x & (kStatShards - 1)) * a.wacc_stride + (size_t)ci * COUT * KH * KW + rest], s);
+            acc_add<ACC_GRAD>(&a.wacc[(size_t)(blockIdx.x & (kStatShards - 1)) * a.wacc_stride + (size_t)ci * COUT * KH * KW + rest], s);
         } else if (a.stats_in) {
             const int jj = j - NACC;
             const int ci = gsel * CT + (jj >> 1);
-            atomicAdd(&a.stats_in[((size_t)(blockIdx.x & (kStatShards - 1)) * CIN + ci) * 4 + 2 + (jj & 1)], s);
+            acc_add<ACC_GRAD>(&a.stats_in[((size_t)(blockIdx.x & (kStatShards - 1)) * CIN + ci) * 4 + 2 + (jj & 1)], s);
         }
     }
 }
@@ -749,11 +749,11 @@ __global__ void __launch_bounds__(256) k_s2_fwd2(S2Fwd a) {
         const int co = i >> 1;
         const int shard = blockIdx.x & (kStatShards - 1);
         if (EPI == S2_RAW_STATS) {
-            atomicAdd(&a.stats[((size_t)shard * COUT + co) * 4 + (i & 1)], s);
+            acc_add<ACC_STAT>(&a.stats[((size_t)shard * COUT + co) * 4 + (i & 1)], s);
         } else if ((i & 1) == 0) {
-            atomicAdd(&a.losses[(size_t)a.st->loss_slot * kStatShards + shard], s);
+            acc_add<ACC_GRAD>(&a.losses[(size_t)a.st->loss_slot * kStatShards + shard], s);
         } else if (EPI == S2_SIGMSE) {
-            atomicAdd(&a.bias_acc[(size_t)shard * a.bias_stride + co], s);
+            acc_add<ACC_GRAD>(&a.bias_acc[(size_t)shard * a.bias_stride + co], s);
         }
     }
 }
@@ -875,10 +875,10 @@ __global__ void __launch_bounds__(256) k_s2_bwd2(S2Bwd a) {
     for (int j = threadIdx.x; j < NRED; j += 256) {
         const double s = (double)redf[j] + (double)redf[NRED + j] + (double)redf[2 * NRED + j] + (double)redf[3 * NRED + j];
         if (j < NACC) {
-            atomicAdd(&a.wacc[(size_t)shard * a.wacc_stride + j], s);
+            acc_add<ACC_GRAD>(&a.wacc[(size_t)shard * a.wacc_stride + j], s);
         } else if (a.stats_in) {
             const int jj = j - NACC;
-            atomicAdd(&a.stats_in[((size_t)shard * CIN + (jj >> 1)) * 4 + 2 + (jj & 1)], s);
+            acc_add<ACC_GRAD>(&a.stats_in[((size_t)shard * CIN + (jj >> 1)) * 4 + 2 + (jj & 1)], s);
         }
     }
 }
@@ -1029,10 +1029,10 @@ __global__ void __launch_bounds__(256) k_s2_bwd_split(S2Bwd a) {
         for (int w = 0; w < WPG; w++) s += (double)redf[(gsel * WPG + w) * NRED + j];
         if (j < NACC) {
             const int c = j / (COUT * KH * KW), rest = j - c * (COUT * KH * KW);
-            atomicAdd(&a.wacc[(size_t)shard * a.wacc_stride + (size_t)(gsel * CT + c) * COUT * KH * KW + rest], s);
+            acc_add<ACC_GRAD>(&a.wacc[(size_t)shard * a.wacc_stride + (size_t)(gsel * CT + c) * COUT * KH * KW + rest], s);
         } else if (a.stats_in) {
             const int jj = j - NACC;
-            atomicAdd(&a.stats_in[((size_t)shard * CIN + gsel * CT + (jj >> 1)) * 4 + 2 + (jj & 1)], s);
+            acc_add<ACC_GRAD>(&a.stats_in[((size_t)shard * CIN + gsel * CT + (jj >> 1)) * 4 + 2 + (jj & 1)], s);
         }
     }
 }
