@@ -125,6 +125,7 @@ SIGNATURES = {
     "vae_set_stream": (C.c_int, [_P, _P]),
     "vae_set_hyper": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.c_double, C.c_uint32]),
+    "vae_set_kernel_mode": (C.c_int, [_P, C.c_int]),
     "vae_set_step": (C.c_int, [_P, C.c_int64]),
     "vae_set_dataset": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
     "vae_train_step": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int]),

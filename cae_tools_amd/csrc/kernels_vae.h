@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "kernels_unet.h"
 
 namespace vae {
@@ -179,6 +181,216 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(const float* __restrict__ X, c
     }
 }
 
+// ---- row-streaming forms of the two MS-SSIM passes (round 3) --------------------------------------------------------------
+// The tile kernels above stage a 26x26 halo in LDS for 16x16 outputs and read it ~90 times per output pixel through the LDS
+// pipe: 278 us for the first scale at the benchmark size, 60 % of what was left of the 'var' step once its trunk ran on the
+// ConvAE kernels.  Both filters are separable, so here a WAVE owns a strip of 64 input columns (54 outputs) and walks down the
+// rows of a band: a lane loads its column's pixel of the row (one coalesced 256-byte run per map), the 11-tap horizontal
+// filter takes its neighbours' values by ten one-lane DPP shifts (no LDS), and the vertical filter reads the last eleven
+// rows' horizontal results from a register ring whose indices are compile-time constants (the row loop is unrolled by
+// eleven).  ~215 vector instructions per row of 54 outputs, no barrier, no LDS.  The arithmetic - every product, every fma and
+// their order - is the tile kernels'; the results agree to fp32 rounding (tests/test_vae_hip_parity.py runs both).
+constexpr int kSsimCols = 64 - kHalo;   // output columns of a wave
+// output rows of a wave (its band) by the map's height: a band of R rows filters R + 10 (tall bands repeat less work, short
+// ones give more waves and a shorter serial walk; measured at the benchmark size, first scale: forward 80 us with 32 rows,
+// 110 with 16; the small scales are bound by the length of the walk, not by its arithmetic)
+inline int ssim_band_rows(int rows, bool forward) { return rows >= 400 ? (forward ? 32 : 16) : (rows >= 200 ? 16 : 8); }
+constexpr int kSsimAhead = 5;           // rows requested ahead of the one being filtered (a wave has one or two peers on its
+                                        // SIMD: with a single row in flight a row cost a memory round trip, 0.66 us)
+
+template <class F, int... I>
+__device__ __forceinline__ void ssim_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void ssim_static_for(F&& f) {
+    ssim_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// lane i <- lane i+1 (lane 63: 0) / lane i <- lane i-1 (lane 0: 0)
+__device__ __forceinline__ float ssim_from_right(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float ssim_from_left(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double ssim_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// grid (ceil(Wv / 54), ceil(bands / 4), BC), block 256: wave w of a workgroup takes band blockIdx.y * 4 + w
+__global__ void __launch_bounds__(256) k_ssim_fwd_rows(const float* __restrict__ X, const float* __restrict__ Y, int H, int W,
+                                                       int rb, Gauss gw, float C1, float C2, int last, double* __restrict__ sums,
+                                                       float* __restrict__ A, float* __restrict__ Bm, float* __restrict__ Cm) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int Hv = H - kHalo, Wv = W - kHalo;
+    const int bc = blockIdx.z;
+    const int x0 = blockIdx.x * kSsimCols, y0 = (blockIdx.y * 4 + wv) * rb;
+    if (y0 >= Hv) return;   // (the kernel has no barrier)
+    const int n_out = min(rb, Hv - y0), n_in = n_out + kHalo;
+    const bool in_ok = x0 + lane < W;
+    const bool out_ok = lane < kSsimCols && x0 + lane < Wv;
+    const size_t in0 = ((size_t)bc * H + y0) * W + (in_ok ? x0 + lane : 0);
+    const float* xp = X + in0;
+    const float* yp = Y + in0;
+    const size_t out0 = ((size_t)bc * Hv + y0) * Wv + (out_ok ? x0 + lane : 0);
+    float ring[kWin][5];
+    float xq[kWin], yq[kWin];              // rows in flight: row r lives in slot r % 11
+    double acc_ssim = 0.0, acc_cs = 0.0;   // (as the tile kernel: every pixel's term enters an fp64 sum)
+#pragma unroll
+    for (int d = 0; d < kSsimAhead; d++) {
+        const bool ok = in_ok && d < n_in;
+        xq[d] = ok ? xp[(size_t)d * W] : 0.f;
+        yq[d] = ok ? yp[(size_t)d * W] : 0.f;
+    }
+    for (int base = 0; base < n_in; base += kWin) {
+        ssim_static_for<kWin>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            const int r = base + s;            // input row y0 + r; r % 11 == s
+            if (r < n_in) {
+                float xs = xq[s], ys = yq[s];
+                {
+                    const bool ok = in_ok && r + kSsimAhead < n_in;
+                    xq[(s + kSsimAhead) % kWin] = ok ? xp[(size_t)(r + kSsimAhead) * W] : 0.f;
+                    yq[(s + kSsimAhead) % kWin] = ok ? yp[(size_t)(r + kSsimAhead) * W] : 0.f;
+                }
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+                for (int t = 0; t < kWin; t++) {
+                    const float g = gw.g[t];
+                    a0 = fmaf(g, xs, a0);
+                    a1 = fmaf(g, ys, a1);
+                    a2 = fmaf(g, xs * xs, a2);
+                    a3 = fmaf(g, ys * ys, a3);
+                    a4 = fmaf(g, xs * ys, a4);
+                    if (t + 1 < kWin) {
+                        xs = ssim_from_right(xs);
+                        ys = ssim_from_right(ys);
+                    }
+                }
+                ring[s][0] = a0, ring[s][1] = a1, ring[s][2] = a2, ring[s][3] = a3, ring[s][4] = a4;
+                if (r >= kHalo) {              // output row y0 + r - 10: input rows r-10 .. r = ring[(s + 1 + t) % 11]
+                    float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < kWin; t++) {
+                        const float g = gw.g[t];
+#pragma unroll
+                        for (int k = 0; k < 5; k++) m[k] = fmaf(g, ring[(s + 1 + t) % kWin][k], m[k]);
+                    }
+                    const float mux = m[0], muy = m[1];
+                    const float sxx = m[2] - mux * mux, syy = m[3] - muy * muy, sxy = m[4] - mux * muy;
+                    const float D2 = sxx + syy + C2, D1 = mux * mux + muy * muy + C1;
+                    const float cs = (2.f * sxy + C2) / D2, l = (2.f * mux * muy + C1) / D1;
+                    if (out_ok) {
+                        acc_ssim += (double)(l * cs);
+                        acc_cs += (double)cs;
+                        const size_t o = out0 + (size_t)(r - kHalo) * Wv;
+                        const float dcs_dgx = (2.f * mux * cs - 2.f * muy) / D2;       // through s_xx and s_xy
+                        if (last) {
+                            const float dl_dmux = 2.f * (muy - l * mux) / D1;
+                            A[o] = cs * dl_dmux + l * dcs_dgx;
+                            Bm[o] = -l * cs / D2;
+                            Cm[o] = l * 2.f / D2;
+                        } else {
+                            A[o] = dcs_dgx;
+                            Bm[o] = -cs / D2;
+                            Cm[o] = 2.f / D2;
+                        }
+                    }
+                }
+            }
+        });
+    }
+    const double t1 = ssim_wave_sum(acc_ssim), t2 = ssim_wave_sum(acc_cs);
+    if (lane == 0) {
+        atomicAdd(&sums[2 * bc], t1);
+        atomicAdd(&sums[2 * bc + 1], t2);
+    }
+}
+
+// Backward of one scale, row-streaming: G(q) = kappa [ (G^T A)(q) + 2 x(q) (G^T Bm)(q) + y(q) (G^T Cm)(q) ] (+ coarse / 4).
+// (G^T M)(q) = sum_t g[t] M(q - t) in both directions: lane l holds map column x0 + l (x0 = 54 * strip - 10; zero outside the
+// valid region), takes its LEFT neighbours by DPP and owns output column x0 + l when l >= 10; rows likewise from a ring.
+// The epilogue's operands (x, y, the coarser scale's gradient) are requested as far ahead as the maps' rows.
+// grid (ceil(W / 54), ceil(bands / 4), BC), block 256
+__global__ void __launch_bounds__(256) k_ssim_bwd_rows(const float* __restrict__ X, const float* __restrict__ Y, int H, int W,
+                                                       int rb, Gauss gw, const float* __restrict__ A, const float* __restrict__ Bm,
+                                                       const float* __restrict__ Cm, const float* __restrict__ kappa, int scale,
+                                                       const float* __restrict__ coarse, float* __restrict__ Gout) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int Hv = H - kHalo, Wv = W - kHalo;
+    const int bc = blockIdx.z;
+    const int x0 = blockIdx.x * kSsimCols - kHalo, y0 = (blockIdx.y * 4 + wv) * rb;   // first map column / first output row
+    if (y0 >= H) return;
+    const int n_out = min(rb, H - y0), n_in = n_out + kHalo;    // map rows y0 - 10 .. y0 + n_out - 1
+    const int px = x0 + lane;
+    const bool in_col = px >= 0 && px < Wv;
+    const bool out_ok = lane >= kHalo && px < W;
+    const float kap = kappa[bc * kScales + scale];
+    const size_t mbase = (size_t)bc * Hv * Wv + (in_col ? px : 0);
+    const size_t obase = (size_t)bc * H * W + (out_ok ? px : 0);
+    const size_t cbase = (size_t)bc * (H / 2) * (W / 2) + (out_ok ? px / 2 : 0);
+    float ring[kWin][3];
+    float aq[kWin], bq[kWin], cq[kWin];    // map rows in flight (row r in slot r % 11)
+    float xe[kWin], ye[kWin], ce[kWin];    // epilogue operands of the output row emitted at step r
+    auto fetch = [&](int r, int slot) {    // map row y0 - 10 + r and, once r >= 10, output row y0 + r - 10
+        const int py = y0 - kHalo + r;
+        const bool ok = r < n_in && in_col && py >= 0 && py < Hv;
+        const size_t o = mbase + (size_t)(ok ? py : 0) * Wv;
+        aq[slot] = ok ? A[o] : 0.f;
+        bq[slot] = ok ? Bm[o] : 0.f;
+        cq[slot] = ok ? Cm[o] : 0.f;
+        const bool eo = r < n_in && r >= kHalo && out_ok;
+        const size_t q = obase + (size_t)(eo ? py : 0) * W;
+        xe[slot] = eo ? X[q] : 0.f;
+        ye[slot] = eo ? Y[q] : 0.f;
+        ce[slot] = eo && coarse ? coarse[cbase + (size_t)(py / 2) * (W / 2)] : 0.f;
+    };
+#pragma unroll
+    for (int d = 0; d < kSsimAhead; d++) fetch(d, d);
+    for (int base = 0; base < n_in; base += kWin) {
+        ssim_static_for<kWin>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            const int r = base + s;
+            if (r < n_in) {
+                float as = aq[s], bs = bq[s], cs = cq[s];
+                const float xv = xe[s], yv = ye[s], cv = ce[s];
+                fetch(r + kSsimAhead, (s + kSsimAhead) % kWin);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int t = 0; t < kWin; t++) {
+                    const float g = gw.g[t];
+                    a0 = fmaf(g, as, a0);
+                    a1 = fmaf(g, bs, a1);
+                    a2 = fmaf(g, cs, a2);
+                    if (t + 1 < kWin) {
+                        as = ssim_from_left(as);
+                        bs = ssim_from_left(bs);
+                        cs = ssim_from_left(cs);
+                    }
+                }
+                ring[s][0] = a0, ring[s][1] = a1, ring[s][2] = a2;
+                if (r >= kHalo) {              // output row qy = y0 + r - 10 = the newest map row: rows qy - t = ring[(s - t) mod 11]
+                    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                    for (int t = 0; t < kWin; t++) {
+                        const float g = gw.g[t];
+                        m0 = fmaf(g, ring[(s + kWin - t) % kWin][0], m0);
+                        m1 = fmaf(g, ring[(s + kWin - t) % kWin][1], m1);
+                        m2 = fmaf(g, ring[(s + kWin - t) % kWin][2], m2);
+                    }
+                    if (out_ok) {
+                        float gq = kap * (m0 + 2.f * xv * m1 + yv * m2);
+                        if (coarse) gq += 0.25f * cv;
+                        Gout[obase + (size_t)(y0 + r - kHalo) * W] = gq;
+                    }
+                }
+            }
+        });
+    }
+}
+
 // per (b,c): f_s = relu(mean), M = prod f_s^w_s, loss += (1 - M)/BC; kappa[bc][s] = -lambda_ssim/BC * w_s * M / f_s / N_s
 // sums: [scale][BC][2]; nvalid[s] = (H_s-10)*(W_s-10).  one block
 __global__ void __launch_bounds__(256) k_msssim_finalize(const double* __restrict__ sums, int BC, const int* __restrict__ nvalid,
@@ -271,19 +483,48 @@ __global__ void __launch_bounds__(256) k_sigmoid_gather(const float* __restrict_
 
 // du = scale * (lambda_mse * 2 (y - t) / n + gssim) * y (1 - y);  mse_out += sum (y-t)^2 / n
 // (scale: the data-parallel weight local / global batch of this rank's gradient, 1 on a single device)
+// du_sum (single-channel outputs): += sum du = the last layer's bias gradient, in the pass that writes du
 __global__ void __launch_bounds__(256) k_vae_loss_grad(const float* __restrict__ y, const float* __restrict__ t,
                                                        const float* __restrict__ gssim, long long n, float lambda_mse, float scale,
-                                                       float* __restrict__ du, double* __restrict__ mse_out) {
+                                                       float* __restrict__ du, double* __restrict__ mse_out,
+                                                       double* __restrict__ du_sum) {
     __shared__ double red[4];
-    double s = 0;
+    double s = 0, sb = 0;
     const float k = 2.f * lambda_mse / (float)n;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float yv = y[i], d = yv - t[i];
         s += (double)d * (double)d;
-        if (du) du[i] = scale * ((k * d + (gssim ? gssim[i] : 0.f)) * yv * (1.f - yv));
+        if (du) {
+            const float g = scale * ((k * d + (gssim ? gssim[i] : 0.f)) * yv * (1.f - yv));
+            du[i] = g;
+            sb += (double)g;
+        }
     }
     const double tt = block_sum(s, red);
     if (threadIdx.x == 0) atomicAdd(mse_out, tt / (double)n);
+    if (du && du_sum) {
+        __syncthreads();
+        const double tb = block_sum(sb, red);
+        if (threadIdx.x == 0) atomicAdd(du_sum, tb);
+    }
+}
+
+// the 2x2 average pooling of both maps of a scale in one launch
+__global__ void __launch_bounds__(256) k_pool2_pair(const float* __restrict__ x, const float* __restrict__ y, int BC, int H, int W,
+                                                    float* __restrict__ xo, float* __restrict__ yo) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)BC * Ho * Wo;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int xq = (int)(o % Wo);
+        const long long r = o / Wo;
+        const int yq = (int)(r % Ho);
+        const long long bc = r / Ho;
+        const size_t i = (size_t)(bc * H + 2 * yq) * W + 2 * xq;
+        const float2 x0 = *reinterpret_cast<const float2*>(x + i), x1 = *reinterpret_cast<const float2*>(x + i + W);
+        const float2 y0 = *reinterpret_cast<const float2*>(y + i), y1 = *reinterpret_cast<const float2*>(y + i + W);
+        xo[o] = 0.25f * (x0.x + x0.y + x1.x + x1.y);
+        yo[o] = 0.25f * (y0.x + y0.y + y1.x + y1.y);
+    }
 }
 
 // g1 = (g1 + g2) * [h > 0]   (two heads read the same ReLU output)

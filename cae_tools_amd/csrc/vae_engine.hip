@@ -67,6 +67,7 @@ struct vae_engine {
     double grad_scale = 1.0;     // data-parallel half-step: every loss gradient is scaled by local / global batch at its source
     uint32_t seed = 0;
     int64_t step = 0;
+    bool row_kernels = true;     // MS-SSIM passes: row-streaming kernels (vae_set_kernel_mode 1) or the LDS tile kernels (0)
     VData ds[2];
     vae::Gauss gauss;
 
@@ -111,16 +112,22 @@ int loss(vae_engine* e, int which, const int32_t* perm, int64_t start, int B, in
     int h = H, w = W;
     for (int s = 0; s < vae::kScales; s++) {
         if (s > 0) {
-            hipLaunchKernelGGL(vae::k_pool2, dim3(blocks_for((long long)BC * h * w / 4)), dim3(256), 0, e->stream, e->f(e->sx[s - 1]),
-                               BC, h, w, e->f(e->sx[s]));
-            hipLaunchKernelGGL(vae::k_pool2, dim3(blocks_for((long long)BC * h * w / 4)), dim3(256), 0, e->stream, e->f(e->sy[s - 1]),
-                               BC, h, w, e->f(e->sy[s]));
+            hipLaunchKernelGGL(vae::k_pool2_pair, dim3(blocks_for((long long)BC * h * w / 4)), dim3(256), 0, e->stream, e->f(e->sx[s - 1]),
+                               e->f(e->sy[s - 1]), BC, h, w, e->f(e->sx[s]), e->f(e->sy[s]));
             h /= 2, w /= 2;
         }
-        const dim3 grid((w - vae::kHalo + vae::kTile - 1) / vae::kTile, (h - vae::kHalo + vae::kTile - 1) / vae::kTile, BC);
-        hipLaunchKernelGGL(vae::k_ssim_fwd, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), h, w, e->gauss, 1e-4f,
-                           9e-4f, s == vae::kScales - 1 ? 1 : 0, ssum + (size_t)s * BC * 2, e->f(e->sA[s]), e->f(e->sB[s]),
-                           e->f(e->sC[s]));
+        double* ss = ssum + (size_t)s * BC * 2;
+        const int lastf = s == vae::kScales - 1 ? 1 : 0;
+        if (e->row_kernels) {
+            const int rb = vae::ssim_band_rows(h - vae::kHalo, true), bands = (h - vae::kHalo + rb - 1) / rb;
+            const dim3 grid((w - vae::kHalo + vae::kSsimCols - 1) / vae::kSsimCols, (bands + 3) / 4, BC);
+            hipLaunchKernelGGL(vae::k_ssim_fwd_rows, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), h, w, rb, e->gauss,
+                               1e-4f, 9e-4f, lastf, ss, e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]));
+        } else {
+            const dim3 grid((w - vae::kHalo + vae::kTile - 1) / vae::kTile, (h - vae::kHalo + vae::kTile - 1) / vae::kTile, BC);
+            hipLaunchKernelGGL(vae::k_ssim_fwd, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), h, w, e->gauss, 1e-4f,
+                               9e-4f, lastf, ss, e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]));
+        }
     }
     int nv[vae::kScales];
     for (int s = 0, hh = H, ww = W; s < vae::kScales; s++, hh /= 2, ww /= 2) nv[s] = (hh - vae::kHalo) * (ww - vae::kHalo);
@@ -130,15 +137,23 @@ int loss(vae_engine* e, int which, const int32_t* perm, int64_t start, int B, in
     if (want_grad) {
         for (int s = vae::kScales - 1; s >= 0; s--) {
             const int hs = H >> s, wsz = W >> s;
-            const dim3 grid((wsz + vae::kTile - 1) / vae::kTile, (hs + vae::kTile - 1) / vae::kTile, BC);
-            hipLaunchKernelGGL(vae::k_ssim_bwd, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), hs, wsz, e->gauss,
-                               e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]), e->f(e->kappa), s,
-                               s == vae::kScales - 1 ? (const float*)nullptr : e->f(e->sG[s + 1]), e->f(e->sG[s]));
+            const float* coarse = s == vae::kScales - 1 ? (const float*)nullptr : e->f(e->sG[s + 1]);
+            if (e->row_kernels) {
+                const int rb = vae::ssim_band_rows(hs, false), bands = (hs + rb - 1) / rb;
+                const dim3 grid((wsz + vae::kSsimCols - 1) / vae::kSsimCols, (bands + 3) / 4, BC);
+                hipLaunchKernelGGL(vae::k_ssim_bwd_rows, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), hs, wsz, rb, e->gauss,
+                                   e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]), e->f(e->kappa), s, coarse, e->f(e->sG[s]));
+            } else {
+                const dim3 grid((wsz + vae::kTile - 1) / vae::kTile, (hs + vae::kTile - 1) / vae::kTile, BC);
+                hipLaunchKernelGGL(vae::k_ssim_bwd, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), hs, wsz, e->gauss,
+                                   e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]), e->f(e->kappa), s, coarse, e->f(e->sG[s]));
+            }
         }
     }
     hipLaunchKernelGGL(vae::k_vae_loss_grad, dim3(blocks_for(n, 1024)), dim3(256), 0, e->stream, e->f(e->sx[0]), e->f(e->sy[0]),
                        want_grad ? e->f(e->sG[0]) : (const float*)nullptr, n, (float)e->l_mse, (float)e->grad_scale,
-                       want_grad ? cae_internal::trunk_output_gradient(e->trunk) : (float*)nullptr, parts + 0);
+                       want_grad ? cae_internal::trunk_output_gradient(e->trunk) : (float*)nullptr, parts + 0,
+                       want_grad && C == 1 ? cae_internal::trunk_output_bias_acc(e->trunk) : (double*)nullptr);
     (void)slot;
     VHIP_TRY(hipGetLastError());
     return CAE_OK;
@@ -177,7 +192,8 @@ int step_common(vae_engine* e, int which, const int32_t* perm, int64_t start, in
         // epilogue; here the loss is ours)
         const int HW = e->out_h * e->out_w;
         const int chunks = (int)std::max<long long>(1, std::min<long long>(((long long)batch * HW + 2047) / 2048, 64));
-        hipLaunchKernelGGL(k_chan_sums, dim3(chunks, e->out_c), dim3(256), 0, e->stream, cae_internal::trunk_output_gradient(e->trunk),
+        if (e->out_c > 1)     // (a single-channel output's sum rides in k_vae_loss_grad)
+            hipLaunchKernelGGL(k_chan_sums, dim3(chunks, e->out_c), dim3(256), 0, e->stream, cae_internal::trunk_output_gradient(e->trunk),
                            (long long)e->out_c * HW, batch, HW, cae_internal::trunk_output_bias_acc(e->trunk), 1, 0);
         if ((rc = cae_internal::trunk_backward(e->trunk, e->f(e->xb), batch))) return rc;
         if (grads_out) {
@@ -280,6 +296,11 @@ int vae_set_hyper(vae_engine* e, double lr, double beta1, double beta2, double e
     if (!e) return vfail(CAE_ERR_ARG, "vae_set_hyper: null engine");
     e->l_mse = lambda_mse, e->l_kl = lambda_kl, e->l_ssim = lambda_ssim, e->seed = noise_seed;
     return cae_set_hyper(e->trunk, lr, beta1, beta2, eps, weight_decay);
+}
+int vae_set_kernel_mode(vae_engine* e, int mode) {
+    if (!e) return vfail(CAE_ERR_ARG, "vae_set_kernel_mode: null engine");
+    e->row_kernels = (mode & 1) != 0;
+    return CAE_OK;
 }
 int vae_set_step(vae_engine* e, int64_t step) {
     if (!e || step < 0) return vfail(CAE_ERR_ARG, "vae_set_step: bad argument");

@@ -115,6 +115,10 @@ class VaeEngine:
         check(self.lib.vae_set_hyper(self.handle, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
                                      float(lambda_mse), float(lambda_kl), float(lambda_ssim), int(seed) & 0xFFFFFFFF))
 
+    def set_kernel_mode(self, mode):
+        """1 (default): row-streaming MS-SSIM kernels; 0: the LDS tile kernels (same results to fp32 rounding; A/B and tests)"""
+        check(self.lib.vae_set_kernel_mode(self.handle, int(mode)))
+
     def set_step(self, step):
         self.steps = int(step)
         check(self.lib.vae_set_step(self.handle, self.steps))

@@ -41,6 +41,10 @@ int vae_bind(vae_engine* e, float* params_dev, float* exp_avg_dev, float* exp_av
 int vae_set_stream(vae_engine* e, void* hip_stream);
 int vae_set_hyper(vae_engine* e, double lr, double beta1, double beta2, double eps, double weight_decay, double lambda_mse,
                   double lambda_kl, double lambda_ssim, uint32_t noise_seed);
+/* 1 (default): the MS-SSIM passes run the row-streaming kernels (a wave walks a strip of 64 columns, DPP neighbours, register
+ * ring); 0: the LDS tile kernels they replaced.  Same arithmetic in the same order: results equal to fp32 rounding (kept
+ * selectable so that the parity tests can say so). */
+int vae_set_kernel_mode(vae_engine* e, int mode);
 int vae_set_step(vae_engine* e, int64_t step);
 int vae_set_dataset(vae_engine* e, int which, const float* x_dev, const float* target_dev, int64_t n);
 /* forward (train mode) + loss + backward + Adam on samples perm[start .. start+batch); the loss slot receives

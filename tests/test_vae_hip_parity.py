@@ -156,3 +156,24 @@ def test_geometry_errors():
     spec = create_model_spec(input_size=(16, 16), input_channels=1, output_size=(100, 100), output_channels=1)
     with pytest.raises(CaeError, match="MS-SSIM"):
         VaeEngine(spec, 8, 4, 2, device="cuda:0")
+
+
+@pytest.mark.parametrize("shape", [((12, 12), (176, 192), 3), ((64, 64), (512, 512), 2)])
+def test_row_streaming_msssim_kernels_equal_the_tile_kernels(shape):
+    """vae_set_kernel_mode: the row-streaming MS-SSIM passes (a wave walks a strip of 64 columns; DPP neighbours, register ring)
+    perform the tile kernels' arithmetic in the tile kernels' order - every loss part and every gradient agree to fp32 rounding
+    (the compiler contracts a few multiply-adds differently in the two kernels: 3e-8 on a loss part).  176x192: strips and bands that end
+    inside a wave, five scales down to 11x12; 512x512: the benchmark geometry (ten strips, sixteen bands)."""
+    (in_size, out_size, B) = shape
+    (fc, latent) = (16, 6)
+    (spec, enc, dec, x, t) = _setup(in_size, out_size, fc, latent, B, seed=21)
+    out = []
+    for mode in (1, 0):
+        eng = _engine(spec, enc, dec, fc, latent, B, lambda_mse=0.7, lambda_kl=0.3, lambda_ssim=1.5, seed=4)
+        eng.set_kernel_mode(mode)
+        eng.set_dataset(0, x, t)
+        g = eng.forward_backward(0, None, 0, B, slot=0).cpu().numpy().astype(np.float64)
+        out.append((np.array(eng.read_losses(0, 1)[0]), g))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-6)
+    scale = np.abs(out[1][1]).max()
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-4, atol=1e-6 * scale)
