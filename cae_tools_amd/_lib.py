@@ -78,6 +78,8 @@ SIGNATURES = {
     "cae_profile_begin": (C.c_int, [_P]),
     "cae_debug_launch_floor": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "cae_profile_end": (C.c_int, [_P, C.POINTER(ProfileRecC), C.c_int]),
+    "cae_trace_range_push": (C.c_int, [C.c_char_p]),
+    "cae_trace_range_pop": (C.c_int, []),
     "cae_scan_f32": (C.c_int, [_P, C.c_int64, _P, C.POINTER(C.c_double)]),
     "cae_normalise_pack": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_float,
                                      C.c_float, C.c_int, _P]),

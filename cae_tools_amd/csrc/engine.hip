@@ -2,6 +2,8 @@
 // and the extern "C" ABI declared in include/cae_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -2491,6 +2493,42 @@ int cae_sync(cae_engine* e) {
 }
 
 int cae_graph_count(const cae_engine* e) { return e ? (int)e->graphs.size() : 0; }
+
+// ---- roctx ranges (SURVEY.md §5 tracing): visible in `rocprofv3 --marker-trace`, free when no profiler is attached ----------
+namespace {
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+    void load() {
+        if (tried) return;
+        tried = true;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+    }
+};
+RoctxApi g_roctx;
+}  // namespace
+
+int cae_trace_range_push(const char* name) {
+    g_roctx.load();
+    if (!g_roctx.push || !name) return 0;
+    g_roctx.push(name);
+    return 1;
+}
+
+int cae_trace_range_pop(void) {
+    if (!g_roctx.pop) return 0;
+    g_roctx.pop();
+    return 1;
+}
 
 int64_t cae_debug_read(cae_engine* e, const char* what, int index, void* host_out, int64_t cap) {
     if (!e || !e->ws || !what || !host_out) return fail(CAE_ERR_ARG, "cae_debug_read: bad argument");

@@ -189,7 +189,8 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(const float* __restrict__ X, c
 // filter takes its neighbours' values by ten one-lane DPP shifts (no LDS), and the vertical filter reads the last eleven
 // rows' horizontal results from a register ring whose indices are compile-time constants (the row loop is unrolled by
 // eleven).  ~215 vector instructions per row of 54 outputs, no barrier, no LDS.  The arithmetic - every product, every fma and
-// their order - is the tile kernels'; the results agree to fp32 rounding (tests/test_vae_hip_parity.py runs both).
+// their order - is the tile kernels' (but for two reciprocals in place of six divisions per pixel); the results agree to fp32
+// rounding (tests/test_vae_hip_parity.py runs both).
 constexpr int kSsimCols = 64 - kHalo;   // output columns of a wave
 // output rows of a wave (its band) by the map's height: a band of R rows filters R + 10 (tall bands repeat less work, short
 // ones give more waves and a shorter serial walk; measured at the benchmark size, first scale: forward 80 us with 32 rows,
@@ -281,21 +282,24 @@ __global__ void __launch_bounds__(256) k_ssim_fwd_rows(const float* __restrict__
                     const float mux = m[0], muy = m[1];
                     const float sxx = m[2] - mux * mux, syy = m[3] - muy * muy, sxy = m[4] - mux * muy;
                     const float D2 = sxx + syy + C2, D1 = mux * mux + muy * muy + C1;
-                    const float cs = (2.f * sxy + C2) / D2, l = (2.f * mux * muy + C1) / D1;
+                    // two divisions per pixel instead of the tile kernel's six (a correctly rounded fp32 division is ~10
+                    // instructions of this VALU-bound walk): the quotients by D2 and D1 become products with 1 / D2, 1 / D1
+                    const float rD2 = 1.f / D2, rD1 = 1.f / D1;
+                    const float cs = (2.f * sxy + C2) * rD2, l = (2.f * mux * muy + C1) * rD1;
                     if (out_ok) {
                         acc_ssim += (double)(l * cs);
                         acc_cs += (double)cs;
                         const size_t o = out0 + (size_t)(r - kHalo) * Wv;
-                        const float dcs_dgx = (2.f * mux * cs - 2.f * muy) / D2;       // through s_xx and s_xy
+                        const float dcs_dgx = (2.f * mux * cs - 2.f * muy) * rD2;       // through s_xx and s_xy
                         if (last) {
-                            const float dl_dmux = 2.f * (muy - l * mux) / D1;
+                            const float dl_dmux = 2.f * (muy - l * mux) * rD1;
                             A[o] = cs * dl_dmux + l * dcs_dgx;
-                            Bm[o] = -l * cs / D2;
-                            Cm[o] = l * 2.f / D2;
+                            Bm[o] = -l * cs * rD2;
+                            Cm[o] = l * 2.f * rD2;
                         } else {
                             A[o] = dcs_dgx;
-                            Bm[o] = -cs / D2;
-                            Cm[o] = 2.f / D2;
+                            Bm[o] = -cs * rD2;
+                            Cm[o] = 2.f * rD2;
                         }
                     }
                 }

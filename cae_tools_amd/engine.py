@@ -306,6 +306,21 @@ class HipEngine(EnginePlan):
                 self._cursor = None     # cae_set_cursor is not a step function: the device cursor may have moved
         return scope()
 
+    def trace_range(self, name):
+        """Context manager: a named roctx range around the host calls made inside (rocprofv3 --marker-trace); a no-op without
+        a roctx library.  ConvAEModel.train marks its passes with it."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            pushed = self.lib.cae_trace_range_push(name.encode())
+            try:
+                yield
+            finally:
+                if pushed:
+                    self.lib.cae_trace_range_pop()
+        return scope()
+
     def graph_count(self):
         return int(self.lib.cae_graph_count(self.handle))
 

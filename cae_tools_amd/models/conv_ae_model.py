@@ -238,11 +238,12 @@ class ConvAEModel(BaseModel):
             par.broadcast_parameters(0)     # rank 0's initial (or loaded) weights and running statistics everywhere
 
         def one_pass(which, idx, n, train):
-            if par is None:
-                return eng.run_batches(which, idx, n, self.batch_size, train=train)
-            if not train:
-                par.broadcast_buffers(0)    # every rank scores with the same running statistics
-            return par.run_batches(which, idx, n, self.batch_size, train=train)
+            with eng.trace_range("cae_tools_amd.train_epoch" if train else "cae_tools_amd.test_epoch"):
+                if par is None:
+                    return eng.run_batches(which, idx, n, self.batch_size, train=train)
+                if not train:
+                    par.broadcast_buffers(0)    # every rank scores with the same running statistics
+                return par.run_batches(which, idx, n, self.batch_size, train=train)
 
         train_loss = test_loss = 0.0
         eng.sync()

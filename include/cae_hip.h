@@ -246,6 +246,12 @@ int cae_profile_begin(cae_engine* e);
 int cae_debug_launch_floor(cae_engine* e, int n, double* micros_per_kernel);
 int cae_profile_end(cae_engine* e, cae_profile_rec* out, int capacity);
 
+/* Tracing (the reference only prints elapsed times: conv_ae_model.py:301,336-341): named host ranges through roctx, bound at
+ * run time (librocprofiler-sdk-roctx.so) - they show up under `rocprofv3 --marker-trace` around the kernels of a pass and
+ * cost nothing without a profiler.  Return 1 when the range was recorded, 0 when no roctx library is present. */
+int cae_trace_range_push(const char* name);
+int cae_trace_range_pop(void);
+
 /* ---- loader kernels (stateless) ---------------------------------------------------------- */
 
 /* ds_dataset.py:43-46,53-58: out3 = {NaN count, nanmin, nanmax} of n floats (blocking). */

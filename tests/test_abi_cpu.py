@@ -59,3 +59,14 @@ def test_bad_geometry_is_rejected():
         EnginePlan(spec, 16, 4, 8)
     with pytest.raises(_lib.CaeError):
         EnginePlan(case.spec, 0, 4, 8)
+
+
+def test_trace_ranges_are_callable_without_a_profiler():
+    """cae_trace_range_push / pop (roctx, bound at run time): balanced calls, 1 when a roctx library was found, 0 otherwise -
+    and never an error: tracing must not be able to break a run"""
+    from cae_tools_amd import _lib
+    lib = _lib.load()
+    pushed = lib.cae_trace_range_push(b"cae_tools_amd.test")
+    assert pushed in (0, 1)
+    assert lib.cae_trace_range_pop() == pushed
+    assert lib.cae_trace_range_push(None) == 0
