@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <map>
@@ -14,6 +15,16 @@
 #include "cae_unet.h"
 #include "kernels_unet.h"
 #include "kernels_unet_mfma.h"
+#include "kernels_unet_skinny.h"
+
+// The ConvAE path's 16x16-tile MFMA GEMM (kernels_gemm.h: four waves split K, one launch for a Linear layer's weight gradient
+// beside its input gradient) for the SMALL Linear layers here (fc -> latent -> fc): the convolution tile engine's strided
+// GEMM policy runs such a layer in a single workgroup's chunk loop, 30-40 us for a few hundred kFLOP.  Its own namespace, as
+// in ctbwd.hip, so that the kernels' host stubs do not collide with engine.hip's.
+namespace ugemm {
+#include "kernels_generic.h"
+#include "kernels_gemm.h"
+}  // namespace ugemm
 
 void cae_detail_set_error(const char* msg);   // engine.hip: message returned by cae_last_error()
 
@@ -96,7 +107,7 @@ struct unet_engine {
     int64_t n_params = 0, n_buffers = 0;
     // workspace
     int64_t ws_bytes = 0;
-    int64_t off_gacc = 0, off_dsum = 0, n_dsum = 0, off_losses = 0, off_ls = 0, off_f32 = 0, off_gscratch = 0;
+    int64_t off_gacc = 0, off_dsum = 0, n_dsum = 0, off_losses = 0, off_ls = 0, off_f32 = 0, off_gscratch = 0, gscratch_bytes = 0;
     int64_t xb = 0, y = 0, coef = 0, scratch = 0;
     char* ws = nullptr;
     float *params = nullptr, *m = nullptr, *v = nullptr, *buffers = nullptr;
@@ -242,7 +253,32 @@ void bn_backward(unet_engine* e, const Bn& bn, const float* gA, long long gAbs, 
                        e->gacc(bn.beta));
 }
 
+// small Linear layers: the whole weight matrix is a few 16x16 tiles' worth (see the include of kernels_gemm.h above)
+// (both sides <= 1024: the 16x16-tile kernel sums K in four fp32 chains of K / 4, fine for a few hundred terms; a K = 6144
+// layer on it put the gradients behind a five-row BatchNorm1d 2-5 % from the oracle where the tile engine's 256-long chains
+// with an fp64 combine stay within 1.5 % - tests/test_unet_hip_parity.py)
+bool small_fc(const Fc& L) { return L.nin <= 1024 && L.nout <= 1024; }
+size_t gemm16_lds() { return (4 * 256 + 256) * sizeof(float) + sizeof(float4); }
+
+ugemm::cae::GemmArgs gemm16_args(int M, int N, int K) {
+    ugemm::cae::GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.M = M, g.N = N, g.K = K;
+    return g;
+}
+
 void lin_fwd(unet_engine* e, const Fc& L, int B, const float* in, float* out) {
+    if (e->specialised && small_fc(L)) {   // out[b][o] = bias[o] + sum_i in[b][i] W[o][i]
+        ugemm::cae::GemmArgs ga = gemm16_args(B, L.nout, L.nin);
+        ga.A = in, ga.sa_m = L.nin, ga.sa_k = 1;
+        ga.B = e->P(L.w), ga.sb_k = 1, ga.sb_n = L.nin;           // B[k][n] = W[n][k]
+        ga.C = out, ga.sc_m = L.nout, ga.sc_n = 1;
+        ga.epi = ugemm::cae::GE_STORE;
+        ga.bias = e->P(L.b);
+        const int tiles = ((B + 15) / 16) * ((L.nout + 15) / 16);
+        hipLaunchKernelGGL(ugemm::cae::k_gemm16, dim3(tiles), dim3(256), gemm16_lds(), e->stream, ga);
+        return;
+    }
     if (e->specialised) {   // out[b][o] = bias[o] + sum_i in[b][i] W[o][i]
         GemmDesc d{L.nout, B, L.nin, e->P(L.w), L.nin, 1, in, 1, L.nin, e->P(L.b), out, nullptr, 1, L.nout, 0};
         gemm_launch(d, reinterpret_cast<double*>(e->ws + e->off_gscratch), e->stream);
@@ -253,6 +289,62 @@ void lin_fwd(unet_engine* e, const Fc& L, int B, const float* in, float* out) {
 }
 
 void lin_bwd(unet_engine* e, const Fc& L, int B, const float* in, const float* gout, float* gin) {
+    if (e->specialised && small_fc(L)) {
+        // dW[o][i] = sum_b gout[b][o] in[b][i], db[o] = sum_b gout[b][o] (a ones column), K = the whole batch in one tile: plain
+        // fp64 stores into the (zeroed) accumulator, one writer per element; beside it gin[b][i] = sum_o gout[b][o] W[o][i]
+        ugemm::cae::GemmArgs gw = gemm16_args(L.nout, L.nin + 1, B);
+        gw.A = gout, gw.sa_m = 1, gw.sa_k = L.nout;
+        gw.B = in, gw.sb_k = L.nin, gw.sb_n = 1;
+        gw.epi = ugemm::cae::GE_ACC64;
+        gw.accW = e->gacc(L.w), gw.accB = e->gacc(L.b), gw.ones_col = 1;
+        const int tiles_w = ((gw.M + 15) / 16) * ((gw.N + 15) / 16);
+        if (!gin) {
+            hipLaunchKernelGGL(ugemm::cae::k_gemm16, dim3(tiles_w), dim3(256), gemm16_lds(), e->stream, gw);
+            return;
+        }
+        ugemm::cae::GemmArgs gd = gemm16_args(B, L.nin, L.nout);
+        gd.A = gout, gd.sa_m = L.nout, gd.sa_k = 1;
+        gd.B = e->P(L.w), gd.sb_k = L.nin, gd.sb_n = 1;           // B[k = o][n = i] = W[o][i]
+        gd.C = gin, gd.sc_m = L.nin, gd.sc_n = 1;
+        gd.epi = ugemm::cae::GE_STORE;
+        const int tiles_d = ((gd.M + 15) / 16) * ((gd.N + 15) / 16);
+        hipLaunchKernelGGL(ugemm::cae::k_gemm16_pair, dim3(tiles_w + tiles_d), dim3(256), gemm16_lds(), e->stream, gw, gd, tiles_w, 0);
+        return;
+    }
+    if (e->specialised && B <= 64) {
+        // the big layers (kernels_unet_skinny.h): the weight gradient as 64x64 output tiles with plain fp64 stores (the
+        // accumulator is zero here and every element has one writer), the input gradient as one pass over W[o][i] rows with
+        // the o range sliced over workgroups and the slices' partial tiles folded in order
+        hipLaunchKernelGGL(k_skinny_outer, dim3((L.nin + 63) / 64, (L.nout + 63) / 64), dim3(256), (size_t)2 * B * 68 * sizeof(float), e->stream, gout, in, B, L.nout,
+                           L.nin, e->gacc(L.w), e->gacc(L.b));
+        if (gin) {
+            const int slices = (L.nout + kSkKs - 1) / kSkKs;
+            static const int wide_env = getenv("CAE_SKINNY_WIDE") ? atoi(getenv("CAE_SKINNY_WIDE")) : 1;   // env: A/B measurements only
+            const bool wide = L.nin >= 256 && wide_env != 0;      // 8 rows x 4 columns per thread, else 4 x 4
+            const int bt = wide ? 8 : 4;
+            int bgs = 1;
+            while (bgs * bt < B) bgs *= 2;
+            const int cols = 4 * (256 / bgs);
+            float* part = nullptr;
+            if (slices > 1) {
+                const long long need = (long long)slices * B * L.nin * (long long)sizeof(float);
+                if (need <= e->gscratch_bytes) part = reinterpret_cast<float*>(e->ws + e->off_gscratch);
+            }
+            if (slices == 1 || part) {
+                const dim3 grid((L.nin + cols - 1) / cols, slices);
+                if (wide) hipLaunchKernelGGL(k_skinny_kj<8>, grid, dim3(256), 0, e->stream, gout, (long long)L.nout, e->P(L.w), B, L.nout, L.nin, bgs, gin, part);
+                else hipLaunchKernelGGL(k_skinny_kj<4>, grid, dim3(256), 0, e->stream, gout, (long long)L.nout, e->P(L.w), B, L.nout, L.nin, bgs, gin, part);
+                if (part) {
+                    const long long n = (long long)B * L.nin;
+                    hipLaunchKernelGGL(k_skinny_fold, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, e->stream, part, slices, n, gin);
+                }
+            } else {
+                GemmDesc d{L.nin, B, L.nout, e->P(L.w), 1, L.nin, gout, 1, L.nout, nullptr, gin, nullptr, 1, L.nin, 0};
+                gemm_launch(d, reinterpret_cast<double*>(e->ws + e->off_gscratch), e->stream);
+            }
+        }
+        return;
+    }
     if (e->specialised) {
         // dW[o][i] += sum_b gout[b][o] in[b][i];  db[o] += sum_b gout[b][o];  gin[b][i] = sum_o gout[b][o] W[o][i]
         GemmDesc w{L.nout, L.nin, B, gout, 1, L.nout, in, L.nin, 1, nullptr, nullptr, e->gacc(L.w), L.nin, 1, 2};
@@ -635,6 +727,7 @@ int unet_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spe
     int64_t gs = 0;   // split-K scratch of the Linear GEMMs: rows x batch doubles, kept zero between uses
     for (int k = 0; k < 4; k++) gs = std::max<int64_t>(gs, (int64_t)std::max(e->fc[k].nin, e->fc[k].nout) * B);
     e->off_gscratch = bytes(gs * 8);
+    e->gscratch_bytes = gs * 8;
     e->off_f32 = bytes(nf * 4);
     e->ws_bytes = off;
     *out = e;

@@ -197,6 +197,13 @@ def test_mfma_path_at_medium_size_against_oracle_and_generic_kernels():
     o.step_count = 2
     (mse, pl, _) = o.loss_and_grads(x, t, m)
     want = o.grads()
+    # the same in fp64: how far the fp32 oracle itself is from the exact gradient on this model (BatchNorm over FIVE rows
+    # behind the first Linear layer makes the Linear section ill-conditioned: 2e-2 of a tensor's maximum is rounding here)
+    to64 = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    o64 = uo.UnetOracle(spec.save(), to64(enc.state_dict()), to64(dec.state_dict()), dropout_rate=0.1, seed=4)
+    o64.step_count = 2
+    o64.loss_and_grads(x.double(), t.double(), m.double())
+    want64 = o64.grads()
     res = {}
     for specialised in (True, False):
         eng = UnetEngine(spec, fc, latent, B, device="cuda:0", specialised=specialised)
@@ -211,8 +218,14 @@ def test_mfma_path_at_medium_size_against_oracle_and_generic_kernels():
             if _feeds_batchnorm(k):
                 continue
             # the generic kernels sum K in one fp32 chain per output (error ~ K * 6e-8 of the operands' scale), the MFMA
-            # ones in chunks; 1.5e-2 of the tensor's largest gradient covers both on this random, unnormalised model
-            _close(res[specialised][0][k].numpy(), w.numpy(), 1.5e-2, 1e-6, f"{k} (specialised={specialised})")
+            # ones in chunks; 1.5e-2 of the tensor's largest gradient covers both on this random, unnormalised model -
+            # or, where the fp32 oracle itself is further than that from the fp64 answer, 3x the oracle's own error
+            (got, w64) = (res[specialised][0][k].numpy().astype(np.float64), want64[k].numpy())
+            own = float(np.abs(w.numpy().astype(np.float64) - w64).max())
+            rel = 1.5e-2
+            tol = max(rel * max(float(np.abs(w64).max()), 1e-6), 3.0 * own)
+            err = float(np.abs(got - w64).max())
+            assert err <= tol, f"{k} (specialised={specialised}): |hip - fp64| {err:.3e} > {tol:.3e} (the fp32 oracle's own {own:.3e})"
     np.testing.assert_allclose(res[True][2], res[False][2], rtol=0, atol=2e-5)
     np.testing.assert_allclose(res[True][2], o.eval_forward(x).numpy(), rtol=0, atol=2e-5)
 
