@@ -384,8 +384,10 @@ __global__ void __launch_bounds__(256) k_bn_act(const float* __restrict__ z, lon
     else body(std::integral_constant<int, 1>{});
 }
 
-// backward, pass 1: g = (gA * dropmask + gB) * [bn(z) > 0]; writes g (contiguous), accumulates
-// sums[c][0..1] += sum g, sum g*xhat.  gA / gB may be null; each has its own batch stride.  grid (chunks, C)
+// backward, pass 1: g = (gA * dropmask + gB) * [bn(z) > 0]; accumulates sums[c][0..1] += sum g, sum g*xhat and, when g_out is
+// given, writes g (contiguous) - since round 3 it is not: pass 2 forms g again from the same operands instead of reading back
+// a map this pass wrote (one tensor-sized write less per BatchNorm layer).  gA / gB may be null; each has its own batch
+// stride.  grid (chunks, C)
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const float* __restrict__ gA, long long gAbs,
                                                        const float* __restrict__ gB, long long gBbs,
                                                        const float* __restrict__ z, long long zbs, int B, int C, int HW,
@@ -417,7 +419,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const float* __restrict__
                 s1 += (double)gv;
                 s2 += (double)gv * (double)xh;
             }
-            g.st(g_out + o);
+            if (g_out) g.st(g_out + o);
         });
     };
     if (vec4_ok(HW, zbs, gA ? gAbs : 0, gB ? gBbs : 0)) body(std::integral_constant<int, 4>{});
@@ -430,16 +432,18 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const float* __restrict__
     }
 }
 
-// backward, pass 2 (in place on g): dz = gamma*invstd*(g - sum_g/N - xhat*sum_gx/N); block x == 0 also
-// adds dgamma = sum g*xhat, dbeta = sum g to the gradient accumulator.  grid (chunks, C)
-__global__ void __launch_bounds__(256) k_bn_bwd_apply(float* __restrict__ g, const float* __restrict__ z, long long zbs,
-                                                      int B, int C, int HW, const float* __restrict__ saved,
-                                                      const float* __restrict__ gamma, const double* __restrict__ sums,
-                                                      double N, double* __restrict__ acc_gamma,
-                                                      double* __restrict__ acc_beta) {
+// backward, pass 2 from the operands of pass 1: dz = gamma*invstd*(g - sum_g/N - xhat*sum_gx/N) with g formed as there;
+// block x == 0 also adds dgamma = sum g*xhat, dbeta = sum g to the gradient accumulator.  grid (chunks, C)
+__global__ void __launch_bounds__(256) k_bn_bwd_apply2(const float* __restrict__ gA, long long gAbs, const float* __restrict__ gB,
+                                                       long long gBbs, const float* __restrict__ z, long long zbs, int B, int C,
+                                                       int HW, const float* __restrict__ saved, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, Drop d, const double* __restrict__ sums,
+                                                       double N, double* __restrict__ acc_gamma, double* __restrict__ acc_beta,
+                                                       float* __restrict__ dz) {
     const int c = blockIdx.y;
     const float mean = saved[2 * c], invstd = saved[2 * c + 1];
-    const float k1 = gamma[c] * invstd;
+    const float ga = gamma[c], be = beta[c];
+    const float k1 = ga * invstd;
     const float m1 = (float)(sums[2 * c] / N), m2 = (float)(sums[2 * c + 1] / N);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         acc_gamma[c] += sums[2 * c + 1];
@@ -448,18 +452,25 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(float* __restrict__ g, con
     auto body = [&](auto VT) {
         constexpr int V = decltype(VT)::value;
         plane_loop<V>(B, HW, [&](int b, int i) {
-            const VecF<V> zt = VecF<V>::ld(z + b * zbs + (long long)c * HW + i);
-            const long long o = ((long long)b * C + c) * HW + i;
-            VecF<V> gt = VecF<V>::ld(g + o);
+            const long long ci = (long long)c * HW + i;
+            const VecF<V> zt = VecF<V>::ld(z + b * zbs + ci);
+            const unsigned long long o = ((unsigned long long)b * C + c) * HW + i;
+            VecF<V> g, ta, tb;
+            if (gA) ta = VecF<V>::ld(gA + b * gAbs + ci);
+            if (gB) tb = VecF<V>::ld(gB + b * gBbs + ci);
 #pragma unroll
             for (int j = 0; j < V; j++) {
                 const float xh = (zt.v[j] - mean) * invstd;
-                gt.v[j] = k1 * (gt.v[j] - m1 - xh * m2);
+                float gv = 0.f;
+                if (gA) gv = ta.v[j] * drop_factor(d, o + j);
+                if (gB) gv += tb.v[j];
+                if (!(fmaf(xh, ga, be) > 0.f)) gv = 0.f;
+                g.v[j] = k1 * (gv - m1 - xh * m2);
             }
-            gt.st(g + o);
+            g.st(dz + o);
         });
     };
-    if (vec4_ok(HW, zbs)) body(std::integral_constant<int, 4>{});
+    if (vec4_ok(HW, zbs, gA ? gAbs : 0, gB ? gBbs : 0)) body(std::integral_constant<int, 4>{});
     else body(std::integral_constant<int, 1>{});
 }
 

@@ -246,11 +246,13 @@ void bn_act(unet_engine* e, const Bn& bn, const float* z, long long zbs, int B, 
 // BatchNorm+ReLU(+dropout) backward: g_io holds dz on return
 void bn_backward(unet_engine* e, const Bn& bn, const float* gA, long long gAbs, const float* gB, long long gBbs,
                  const float* z, long long zbs, int B, int HW, Drop d, float* g_io) {
+    // pass 1 only sums; pass 2 forms the masked gradient again from gA / gB / z and writes dz (g_io may alias neither input:
+    // the callers pass distinct buffers)
     hipLaunchKernelGGL(k_bn_bwd_reduce, ew_grid(B, bn.C, HW), dim3(256), 0, e->stream, gA, gAbs, gB, gBbs, z, zbs, B, bn.C,
-                       HW, e->f(bn.saved), e->P(bn.gamma), e->P(bn.beta), d, g_io, e->dsum(bn.bsums));
-    hipLaunchKernelGGL(k_bn_bwd_apply, ew_grid(B, bn.C, HW), dim3(256), 0, e->stream, g_io, z, zbs, B, bn.C, HW,
-                       e->f(bn.saved), e->P(bn.gamma), e->dsum(bn.bsums), (double)B * HW, e->gacc(bn.gamma),
-                       e->gacc(bn.beta));
+                       HW, e->f(bn.saved), e->P(bn.gamma), e->P(bn.beta), d, (float*)nullptr, e->dsum(bn.bsums));
+    hipLaunchKernelGGL(k_bn_bwd_apply2, ew_grid(B, bn.C, HW), dim3(256), 0, e->stream, gA, gAbs, gB, gBbs, z, zbs, B, bn.C, HW,
+                       e->f(bn.saved), e->P(bn.gamma), e->P(bn.beta), d, e->dsum(bn.bsums), (double)B * HW, e->gacc(bn.gamma),
+                       e->gacc(bn.beta), g_io);
 }
 
 // small Linear layers: the whole weight matrix is a few 16x16 tiles' worth (see the include of kernels_gemm.h above)
