@@ -220,15 +220,14 @@ __device__ __forceinline__ double ssim_wave_sum(double v) {
     return v;
 }
 
-// grid (ceil(Wv / 54), ceil(bands / 4), BC), block 256: wave w of a workgroup takes band blockIdx.y * 4 + w
-__global__ void __launch_bounds__(256) k_ssim_fwd_rows(const float* __restrict__ X, const float* __restrict__ Y, int H, int W,
-                                                       int rb, Gauss gw, float C1, float C2, int last, double* __restrict__ sums,
-                                                       float* __restrict__ A, float* __restrict__ Bm, float* __restrict__ Cm) {
+// one scale's forward walk of image bc: wave w of the workgroup takes band blockIdx.y * 4 + w of strip blockIdx.x
+__device__ __forceinline__ void ssim_fwd_rows_body(const float* __restrict__ X, const float* __restrict__ Y, int H, int W, int rb,
+                                                   const Gauss& gw, float C1, float C2, int last, double* __restrict__ sums,
+                                                   float* __restrict__ A, float* __restrict__ Bm, float* __restrict__ Cm, int bc) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int Hv = H - kHalo, Wv = W - kHalo;
-    const int bc = blockIdx.z;
     const int x0 = blockIdx.x * kSsimCols, y0 = (blockIdx.y * 4 + wv) * rb;
-    if (y0 >= Hv) return;   // (the kernel has no barrier)
+    if (y0 >= Hv || x0 >= Wv) return;   // (the kernel has no barrier)
     const int n_out = min(rb, Hv - y0), n_in = n_out + kHalo;
     const bool in_ok = x0 + lane < W;
     const bool out_ok = lane < kSsimCols && x0 + lane < Wv;
@@ -310,6 +309,68 @@ __global__ void __launch_bounds__(256) k_ssim_fwd_rows(const float* __restrict__
     if (lane == 0) {
         atomicAdd(&sums[2 * bc], t1);
         atomicAdd(&sums[2 * bc + 1], t2);
+    }
+}
+
+// grid (ceil(Wv / 54), ceil(bands / 4), BC), block 256
+__global__ void __launch_bounds__(256) k_ssim_fwd_rows(const float* __restrict__ X, const float* __restrict__ Y, int H, int W,
+                                                       int rb, Gauss gw, float C1, float C2, int last, double* __restrict__ sums,
+                                                       float* __restrict__ A, float* __restrict__ Bm, float* __restrict__ Cm) {
+    ssim_fwd_rows_body(X, Y, H, W, rb, gw, C1, C2, last, sums, A, Bm, Cm, blockIdx.z);
+}
+
+// The coarse scales in ONE launch: they are independent of one another once the pooled maps exist, and each is bound by the
+// length of its serial walk (10-16 us per launch for 16 images of 256 x 256 and smaller), not by its arithmetic.
+// grid (strips of the largest scale, band groups of the largest scale, BC * n): blockIdx.z = scale slot * BC + bc; workgroups
+// outside a smaller scale's extent leave at once.
+struct SsimScale {
+    const float* X;
+    const float* Y;
+    int H, W, rb, last;
+    double* sums;
+    float *A, *Bm, *Cm;
+};
+struct SsimScales {
+    SsimScale s[kScales];
+    int n, BC;
+};
+__global__ void __launch_bounds__(256) k_ssim_fwd_rows_multi(SsimScales set, Gauss gw, float C1, float C2) {
+    const int slot = blockIdx.z / set.BC, bc = blockIdx.z - slot * set.BC;
+    const SsimScale& p = set.s[slot];
+    ssim_fwd_rows_body(p.X, p.Y, p.H, p.W, p.rb, gw, C1, C2, p.last, p.sums, p.A, p.Bm, p.Cm, bc);
+}
+
+// The whole pooling pyramid of both maps in one launch: a workgroup takes a 16 x 16 block of the finest map and writes its
+// 8 x 8, 4 x 4, 2 x 2 and 1 x 1 averages (each level the 2 x 2 average of the level above, as k_pool2 computes them one launch
+// per level).  H, W multiples of 16.  grid (W / 16, H / 16, BC), block 256
+struct Pyramid {
+    float* x[kScales];   // [1..4] written, [0] read
+    float* y[kScales];
+};
+__global__ void __launch_bounds__(256) k_pool_pyramid(Pyramid pm, int H, int W) {
+    __shared__ float sx[2][16][17], sy[2][16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int bc = blockIdx.z;
+    const size_t o0 = ((size_t)bc * H + blockIdx.y * 16 + ty) * W + blockIdx.x * 16 + tx;
+    sx[0][ty][tx] = pm.x[0][o0];
+    sy[0][ty][tx] = pm.y[0][o0];
+    __syncthreads();
+    int cur = 0;
+#pragma unroll
+    for (int lvl = 1; lvl < kScales; lvl++) {
+        const int n = 16 >> lvl;                       // side of this level's block
+        if (tx < n && ty < n) {
+            const float vx = 0.25f * (sx[cur][2 * ty][2 * tx] + sx[cur][2 * ty][2 * tx + 1] + sx[cur][2 * ty + 1][2 * tx] + sx[cur][2 * ty + 1][2 * tx + 1]);
+            const float vy = 0.25f * (sy[cur][2 * ty][2 * tx] + sy[cur][2 * ty][2 * tx + 1] + sy[cur][2 * ty + 1][2 * tx] + sy[cur][2 * ty + 1][2 * tx + 1]);
+            sx[cur ^ 1][ty][tx] = vx;
+            sy[cur ^ 1][ty][tx] = vy;
+            const int Hl = H >> lvl, Wl = W >> lvl;
+            const size_t o = ((size_t)bc * Hl + blockIdx.y * n + ty) * Wl + blockIdx.x * n + tx;
+            pm.x[lvl][o] = vx;
+            pm.y[lvl][o] = vy;
+        }
+        __syncthreads();
+        cur ^= 1;
     }
 }
 

@@ -109,24 +109,43 @@ int loss(vae_engine* e, int which, const int32_t* perm, int64_t start, int B, in
                        (long long)start, B, E, e->f(e->sx[0]), e->f(e->sy[0]));
     double* ssum = reinterpret_cast<double*>(e->ws + e->off_ssum);
     VHIP_TRY(hipMemsetAsync(ssum, 0, (size_t)vae::kScales * BC * 2 * sizeof(double), e->stream));
-    int h = H, w = W;
-    for (int s = 0; s < vae::kScales; s++) {
-        if (s > 0) {
-            hipLaunchKernelGGL(vae::k_pool2_pair, dim3(blocks_for((long long)BC * h * w / 4)), dim3(256), 0, e->stream, e->f(e->sx[s - 1]),
-                               e->f(e->sy[s - 1]), BC, h, w, e->f(e->sx[s]), e->f(e->sy[s]));
-            h /= 2, w /= 2;
-        }
-        double* ss = ssum + (size_t)s * BC * 2;
-        const int lastf = s == vae::kScales - 1 ? 1 : 0;
-        if (e->row_kernels) {
+    if (e->row_kernels) {
+        // the pooling pyramid of both maps in one launch, the finest scale's walk, then the four coarse scales' walks in one launch
+        vae::Pyramid pm;
+        for (int s = 0; s < vae::kScales; s++) pm.x[s] = e->f(e->sx[s]), pm.y[s] = e->f(e->sy[s]);
+        hipLaunchKernelGGL(vae::k_pool_pyramid, dim3(W / 16, H / 16, BC), dim3(256), 0, e->stream, pm, H, W);
+        vae::SsimScales set;
+        memset(&set, 0, sizeof set);
+        set.BC = BC;
+        dim3 coarse_grid(1, 1, 1);
+        for (int s = 0, h = H, w = W; s < vae::kScales; s++, h /= 2, w /= 2) {
             const int rb = vae::ssim_band_rows(h - vae::kHalo, true), bands = (h - vae::kHalo + rb - 1) / rb;
             const dim3 grid((w - vae::kHalo + vae::kSsimCols - 1) / vae::kSsimCols, (bands + 3) / 4, BC);
-            hipLaunchKernelGGL(vae::k_ssim_fwd_rows, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), h, w, rb, e->gauss,
-                               1e-4f, 9e-4f, lastf, ss, e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]));
-        } else {
+            double* ss = ssum + (size_t)s * BC * 2;
+            const int lastf = s == vae::kScales - 1 ? 1 : 0;
+            if (s == 0) {
+                hipLaunchKernelGGL(vae::k_ssim_fwd_rows, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), h, w, rb, e->gauss,
+                                   1e-4f, 9e-4f, lastf, ss, e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]));
+            } else {
+                set.s[set.n++] = vae::SsimScale{e->f(e->sx[s]), e->f(e->sy[s]), h, w, rb, lastf, ss, e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s])};
+                coarse_grid.x = std::max(coarse_grid.x, grid.x);
+                coarse_grid.y = std::max(coarse_grid.y, grid.y);
+            }
+        }
+        coarse_grid.z = (unsigned)(BC * set.n);
+        hipLaunchKernelGGL(vae::k_ssim_fwd_rows_multi, coarse_grid, dim3(256), 0, e->stream, set, e->gauss, 1e-4f, 9e-4f);
+    } else {
+        int h = H, w = W;
+        for (int s = 0; s < vae::kScales; s++) {
+            if (s > 0) {
+                hipLaunchKernelGGL(vae::k_pool2_pair, dim3(blocks_for((long long)BC * h * w / 4)), dim3(256), 0, e->stream, e->f(e->sx[s - 1]),
+                                   e->f(e->sy[s - 1]), BC, h, w, e->f(e->sx[s]), e->f(e->sy[s]));
+                h /= 2, w /= 2;
+            }
             const dim3 grid((w - vae::kHalo + vae::kTile - 1) / vae::kTile, (h - vae::kHalo + vae::kTile - 1) / vae::kTile, BC);
             hipLaunchKernelGGL(vae::k_ssim_fwd, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), h, w, e->gauss, 1e-4f,
-                               9e-4f, lastf, ss, e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]));
+                               9e-4f, s == vae::kScales - 1 ? 1 : 0, ssum + (size_t)s * BC * 2, e->f(e->sA[s]), e->f(e->sB[s]),
+                               e->f(e->sC[s]));
         }
     }
     int nv[vae::kScales];
