@@ -35,9 +35,10 @@ constexpr int kStatShards = 8;
 //             (N E[y^2] of a layer: 2e6 values of order 1 at the benchmark size);
 //   ACC_GRAD  everything gradient-sized - sum g and sum g x_hat of BatchNorm backward (slots 2, 3), weight and bias gradients,
 //             the loss: q = 2^-50 (8.9e-16), exact while |sum| < 8.
-// A sum that leaves its window is not wrong, it merely rounds as fp64 sums always did (reproducible to ~1e-16 again); the
-// resolution costs at most 0.5 q per addend (a few thousand addends per sum: 1e-12 relative on the statistics of the
-// smallest layer, 1e-9 on a gradient element of 1e-6).
+// A sum that leaves its window is not wrong, it merely rounds as fp64 sums always did (reproducible to ~1e-16 again).  The
+// resolution costs at most 0.5 q per addend, and an addend covers >= 16 values, so E[y^2] and the mean carry an absolute error
+// of at most 1.2e-10: on the variance of a layer with outputs of order 1 that is 1e-10 relative; in the worst case (a layer
+// whose variance is far below BatchNorm's eps = 1e-5) 1 / sqrt(var + eps) moves by 6e-6.  Gradient sums: 4e-16 per addend.
 enum AccKind : int { ACC_STAT = 0, ACC_GRAD = 1 };
 template <int KIND>
 __device__ __forceinline__ double acc_grid(double v) {
