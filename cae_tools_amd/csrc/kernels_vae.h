@@ -344,16 +344,35 @@ __global__ void __launch_bounds__(256) k_ssim_fwd_rows_multi(SsimScales set, Gau
 // 8 x 8, 4 x 4, 2 x 2 and 1 x 1 averages (each level the 2 x 2 average of the level above, as k_pool2 computes them one launch
 // per level).  H, W multiples of 16.  grid (W / 16, H / 16, BC), block 256
 struct Pyramid {
-    float* x[kScales];   // [1..4] written, [0] read
+    float* x[kScales];   // [1..4] written; [0] read, or written too when the finest level is formed here (below)
     float* y[kScales];
+    // finest level formed in this pass: x[0] = sigmoid(u), y[0] = the target rows of samples perm[start + b] (what
+    // k_sigmoid_gather does in a launch of its own); u == nullptr: x[0], y[0] are inputs.  E = C * H * W elements per sample.
+    const float* u;
+    const float* target;
+    const int* perm;
+    long long start;
+    int C;
 };
 __global__ void __launch_bounds__(256) k_pool_pyramid(Pyramid pm, int H, int W) {
     __shared__ float sx[2][16][17], sy[2][16][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int bc = blockIdx.z;
-    const size_t o0 = ((size_t)bc * H + blockIdx.y * 16 + ty) * W + blockIdx.x * 16 + tx;
-    sx[0][ty][tx] = pm.x[0][o0];
-    sy[0][ty][tx] = pm.y[0][o0];
+    const size_t in_img = (size_t)(blockIdx.y * 16 + ty) * W + blockIdx.x * 16 + tx;
+    const size_t o0 = (size_t)bc * H * W + in_img;
+    if (pm.u) {
+        const int b = bc / pm.C, c = bc - b * pm.C;
+        const long long smp = pm.perm ? (long long)pm.perm[pm.start + b] : pm.start + b;
+        const float yv = 1.f / (1.f + expf(-pm.u[o0]));
+        const float tv = pm.target[((size_t)smp * pm.C + c) * H * W + in_img];
+        pm.x[0][o0] = yv;
+        pm.y[0][o0] = tv;
+        sx[0][ty][tx] = yv;
+        sy[0][ty][tx] = tv;
+    } else {
+        sx[0][ty][tx] = pm.x[0][o0];
+        sy[0][ty][tx] = pm.y[0][o0];
+    }
     __syncthreads();
     int cur = 0;
 #pragma unroll

@@ -105,14 +105,16 @@ void hook_reparam_bwd(void* user, hipStream_t s, const float* gz, const float* h
 int loss(vae_engine* e, int which, const int32_t* perm, int64_t start, int B, int slot, bool want_grad, double* parts) {
     const int C = e->out_c, H = e->out_h, W = e->out_w, BC = B * C;
     const long long E = (long long)C * H * W, n = (long long)B * E;
-    hipLaunchKernelGGL(vae::k_sigmoid_gather, dim3(blocks_for(n)), dim3(256), 0, e->stream, cae_internal::trunk_raw_output(e->trunk), e->ds[which].t, perm,
-                       (long long)start, B, E, e->f(e->sx[0]), e->f(e->sy[0]));
+    if (!e->row_kernels)   // (the row-kernel path forms the finest level inside its pyramid launch)
+        hipLaunchKernelGGL(vae::k_sigmoid_gather, dim3(blocks_for(n)), dim3(256), 0, e->stream, cae_internal::trunk_raw_output(e->trunk), e->ds[which].t, perm,
+                           (long long)start, B, E, e->f(e->sx[0]), e->f(e->sy[0]));
     double* ssum = reinterpret_cast<double*>(e->ws + e->off_ssum);
     VHIP_TRY(hipMemsetAsync(ssum, 0, (size_t)vae::kScales * BC * 2 * sizeof(double), e->stream));
     if (e->row_kernels) {
         // the pooling pyramid of both maps in one launch, the finest scale's walk, then the four coarse scales' walks in one launch
         vae::Pyramid pm;
         for (int s = 0; s < vae::kScales; s++) pm.x[s] = e->f(e->sx[s]), pm.y[s] = e->f(e->sy[s]);
+        pm.u = cae_internal::trunk_raw_output(e->trunk), pm.target = e->ds[which].t, pm.perm = perm, pm.start = start, pm.C = C;
         hipLaunchKernelGGL(vae::k_pool_pyramid, dim3(W / 16, H / 16, BC), dim3(256), 0, e->stream, pm, H, W);
         vae::SsimScales set;
         memset(&set, 0, sizeof set);
