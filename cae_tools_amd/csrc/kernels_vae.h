@@ -397,16 +397,14 @@ __global__ void __launch_bounds__(256) k_pool_pyramid(Pyramid pm, int H, int W) 
 // (G^T M)(q) = sum_t g[t] M(q - t) in both directions: lane l holds map column x0 + l (x0 = 54 * strip - 10; zero outside the
 // valid region), takes its LEFT neighbours by DPP and owns output column x0 + l when l >= 10; rows likewise from a ring.
 // The epilogue's operands (x, y, the coarser scale's gradient) are requested as far ahead as the maps' rows.
-// grid (ceil(W / 54), ceil(bands / 4), BC), block 256
-__global__ void __launch_bounds__(256) k_ssim_bwd_rows(const float* __restrict__ X, const float* __restrict__ Y, int H, int W,
-                                                       int rb, Gauss gw, const float* __restrict__ A, const float* __restrict__ Bm,
-                                                       const float* __restrict__ Cm, const float* __restrict__ kappa, int scale,
-                                                       const float* __restrict__ coarse, float* __restrict__ Gout) {
+__device__ __forceinline__ void ssim_bwd_rows_body(const float* __restrict__ X, const float* __restrict__ Y, int H, int W, int rb,
+                                                   const Gauss& gw, const float* __restrict__ A, const float* __restrict__ Bm,
+                                                   const float* __restrict__ Cm, const float* __restrict__ kappa, int scale,
+                                                   const float* __restrict__ coarse, float* __restrict__ Gout, int bc) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int Hv = H - kHalo, Wv = W - kHalo;
-    const int bc = blockIdx.z;
     const int x0 = blockIdx.x * kSsimCols - kHalo, y0 = (blockIdx.y * 4 + wv) * rb;   // first map column / first output row
-    if (y0 >= H) return;
+    if (y0 >= H || x0 + kHalo >= W) return;
     const int n_out = min(rb, H - y0), n_in = n_out + kHalo;    // map rows y0 - 10 .. y0 + n_out - 1
     const int px = x0 + lane;
     const bool in_col = px >= 0 && px < Wv;
@@ -472,6 +470,51 @@ __global__ void __launch_bounds__(256) k_ssim_bwd_rows(const float* __restrict__
                 }
             }
         });
+    }
+}
+
+// grid (ceil(W / 54), ceil(bands / 4), BC), block 256
+__global__ void __launch_bounds__(256) k_ssim_bwd_rows(const float* __restrict__ X, const float* __restrict__ Y, int H, int W,
+                                                       int rb, Gauss gw, const float* __restrict__ A, const float* __restrict__ Bm,
+                                                       const float* __restrict__ Cm, const float* __restrict__ kappa, int scale,
+                                                       const float* __restrict__ coarse, float* __restrict__ Gout) {
+    ssim_bwd_rows_body(X, Y, H, W, rb, gw, A, Bm, Cm, kappa, scale, coarse, Gout, blockIdx.z);
+}
+
+// The coarse scales' OWN terms kappa_s (G^T A + 2 x G^T Bm + y G^T Cm) in one launch (they do not depend on one another; what
+// chains the scales is only the pooling term, added by k_ssim_combine).  grid as k_ssim_fwd_rows_multi.
+struct SsimBwdScale {
+    const float* X;
+    const float* Y;
+    int H, W, rb, scale;
+    const float *A, *Bm, *Cm;
+    float* G;
+};
+struct SsimBwdScales {
+    SsimBwdScale s[kScales];
+    int n, BC;
+};
+__global__ void __launch_bounds__(256) k_ssim_bwd_rows_multi(SsimBwdScales set, Gauss gw, const float* __restrict__ kappa) {
+    const int slot = blockIdx.z / set.BC, bc = blockIdx.z - slot * set.BC;
+    const SsimBwdScale& p = set.s[slot];
+    ssim_bwd_rows_body(p.X, p.Y, p.H, p.W, p.rb, gw, p.A, p.Bm, p.Cm, kappa, p.scale, nullptr, p.G, bc);
+}
+
+// G1(q) = own1(q) + 1/4 (own2(q/2) + 1/4 (own3(q/4) + 1/4 own4(q/8))): the pooling chain of scales 4 -> 1, nested exactly as the
+// per-scale launches added it (G_s = own_s + G_{s+1} / 4), in place on own1.  (BC, H1, W1) with H1, W1 multiples of 8.
+__global__ void __launch_bounds__(256) k_ssim_combine(float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ g3,
+                                                      const float* __restrict__ g4, int BC, int H1, int W1) {
+    const long long total = (long long)BC * H1 * W1;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int x = (int)(o % W1);
+        const long long r = o / W1;
+        const int y = (int)(r % H1);
+        const long long bc = r / H1;
+        float g3v = g3[(bc * (H1 / 4) + y / 4) * (W1 / 4) + x / 4];
+        g3v += 0.25f * g4[(bc * (H1 / 8) + y / 8) * (W1 / 8) + x / 8];
+        float g2v = g2[(bc * (H1 / 2) + y / 2) * (W1 / 2) + x / 2];
+        g2v += 0.25f * g3v;
+        g1[o] += 0.25f * g2v;
     }
 }
 

@@ -155,20 +155,37 @@ int loss(vae_engine* e, int which, const int32_t* perm, int64_t start, int B, in
     VHIP_TRY(hipMemcpyAsync(e->f(e->nvalid), nv, sizeof nv, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(vae::k_msssim_finalize, dim3(1), dim3(256), 0, e->stream, ssum, BC, reinterpret_cast<const int*>(e->f(e->nvalid)),
                        (float)e->l_ssim, parts + 2, e->f(e->kappa));
-    if (want_grad) {
+    if (want_grad && e->row_kernels) {
+        // the four coarse scales' own terms in one launch, their pooling chain folded into scale 1's map, then the finest scale
+        vae::SsimBwdScales set;
+        memset(&set, 0, sizeof set);
+        set.BC = BC;
+        dim3 cg(1, 1, 1);
+        for (int s = 1; s < vae::kScales; s++) {
+            const int hs = H >> s, wsz = W >> s;
+            const int rb = vae::ssim_band_rows(hs, false), bands = (hs + rb - 1) / rb;
+            set.s[set.n++] = vae::SsimBwdScale{e->f(e->sx[s]), e->f(e->sy[s]), hs, wsz, rb, s, e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]),
+                                               e->f(e->sG[s])};
+            cg.x = std::max<unsigned>(cg.x, (wsz + vae::kSsimCols - 1) / vae::kSsimCols);
+            cg.y = std::max<unsigned>(cg.y, (bands + 3) / 4);
+        }
+        cg.z = (unsigned)(BC * set.n);
+        hipLaunchKernelGGL(vae::k_ssim_bwd_rows_multi, cg, dim3(256), 0, e->stream, set, e->gauss, e->f(e->kappa));
+        hipLaunchKernelGGL(vae::k_ssim_combine, dim3(blocks_for((long long)BC * (H / 2) * (W / 2))), dim3(256), 0, e->stream, e->f(e->sG[1]),
+                           e->f(e->sG[2]), e->f(e->sG[3]), e->f(e->sG[4]), BC, H / 2, W / 2);
+        {
+            const int rb = vae::ssim_band_rows(H, false), bands = (H + rb - 1) / rb;
+            const dim3 grid((W + vae::kSsimCols - 1) / vae::kSsimCols, (bands + 3) / 4, BC);
+            hipLaunchKernelGGL(vae::k_ssim_bwd_rows, grid, dim3(256), 0, e->stream, e->f(e->sx[0]), e->f(e->sy[0]), H, W, rb, e->gauss,
+                               e->f(e->sA[0]), e->f(e->sB[0]), e->f(e->sC[0]), e->f(e->kappa), 0, e->f(e->sG[1]), e->f(e->sG[0]));
+        }
+    } else if (want_grad) {
         for (int s = vae::kScales - 1; s >= 0; s--) {
             const int hs = H >> s, wsz = W >> s;
             const float* coarse = s == vae::kScales - 1 ? (const float*)nullptr : e->f(e->sG[s + 1]);
-            if (e->row_kernels) {
-                const int rb = vae::ssim_band_rows(hs, false), bands = (hs + rb - 1) / rb;
-                const dim3 grid((wsz + vae::kSsimCols - 1) / vae::kSsimCols, (bands + 3) / 4, BC);
-                hipLaunchKernelGGL(vae::k_ssim_bwd_rows, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), hs, wsz, rb, e->gauss,
-                                   e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]), e->f(e->kappa), s, coarse, e->f(e->sG[s]));
-            } else {
-                const dim3 grid((wsz + vae::kTile - 1) / vae::kTile, (hs + vae::kTile - 1) / vae::kTile, BC);
-                hipLaunchKernelGGL(vae::k_ssim_bwd, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), hs, wsz, e->gauss,
-                                   e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]), e->f(e->kappa), s, coarse, e->f(e->sG[s]));
-            }
+            const dim3 grid((wsz + vae::kTile - 1) / vae::kTile, (hs + vae::kTile - 1) / vae::kTile, BC);
+            hipLaunchKernelGGL(vae::k_ssim_bwd, grid, dim3(256), 0, e->stream, e->f(e->sx[s]), e->f(e->sy[s]), hs, wsz, e->gauss,
+                               e->f(e->sA[s]), e->f(e->sB[s]), e->f(e->sC[s]), e->f(e->kappa), s, coarse, e->f(e->sG[s]));
         }
     }
     hipLaunchKernelGGL(vae::k_vae_loss_grad, dim3(blocks_for(n, 1024)), dim3(256), 0, e->stream, e->f(e->sx[0]), e->f(e->sy[0]),
