@@ -519,22 +519,25 @@ __global__ void __launch_bounds__(256) k_ssim_combine(float* __restrict__ g1, co
 }
 
 // per (b,c): f_s = relu(mean), M = prod f_s^w_s, loss += (1 - M)/BC; kappa[bc][s] = -lambda_ssim/BC * w_s * M / f_s / N_s
-// sums: [scale][BC][2]; nvalid[s] = (H_s-10)*(W_s-10).  one block
-__global__ void __launch_bounds__(256) k_msssim_finalize(const double* __restrict__ sums, int BC, const int* __restrict__ nvalid,
+// sums: [scale][BC][2]; nvalid.v[s] = (H_s-10)*(W_s-10), a kernel argument (no per-step host-to-device copy).  one block
+struct ScaleCounts {
+    int v[kScales];
+};
+__global__ void __launch_bounds__(256) k_msssim_finalize(const double* __restrict__ sums, int BC, ScaleCounts nvalid,
                                                          float lambda_ssim, double* __restrict__ loss_out, float* __restrict__ kappa) {
     __shared__ double red[4];
     double acc = 0;
     for (int bc = threadIdx.x; bc < BC; bc += 256) {
         double f[kScales], M = 1.0;
         for (int s = 0; s < kScales; s++) {
-            const double v = sums[((size_t)s * BC + bc) * 2 + (s == kScales - 1 ? 0 : 1)] / (double)nvalid[s];
+            const double v = sums[((size_t)s * BC + bc) * 2 + (s == kScales - 1 ? 0 : 1)] / (double)nvalid.v[s];
             f[s] = v > 0.0 ? v : 0.0;
             M *= pow(f[s], (double)c_ms_weights[s]);
         }
         acc += 1.0 - M;
         for (int s = 0; s < kScales; s++)
             kappa[bc * kScales + s] =
-                f[s] > 0.0 ? (float)(-(double)lambda_ssim / BC * c_ms_weights[s] * M / f[s] / (double)nvalid[s]) : 0.f;
+                f[s] > 0.0 ? (float)(-(double)lambda_ssim / BC * c_ms_weights[s] * M / f[s] / (double)nvalid.v[s]) : 0.f;
     }
     const double t = block_sum(acc, red);
     if (threadIdx.x == 0) *loss_out = t / (double)BC;

@@ -57,7 +57,7 @@ struct vae_engine {
     int in_c = 0, in_h = 0, in_w = 0, out_c = 0, out_h = 0, out_w = 0;
     int64_t n_params = 0, n_buffers = 0, ws_bytes = 0, trunk_ws = 0;
     int64_t off_trunk = 0, off_grads = 0, off_losses = 0, off_f32 = 0;
-    int64_t xb = 0, eps = 0, kappa = 0, nvalid = 0;
+    int64_t xb = 0, eps = 0, kappa = 0;
     int64_t sx[vae::kScales] = {0}, sy[vae::kScales] = {0}, sA[vae::kScales] = {0}, sB[vae::kScales] = {0},
             sC[vae::kScales] = {0}, sG[vae::kScales] = {0};
     int64_t off_ssum = 0, off_part = 0;   // doubles: [scale][BC][2]; parts {mse, kl, ssim}
@@ -108,8 +108,7 @@ int loss(vae_engine* e, int which, const int32_t* perm, int64_t start, int B, in
     if (!e->row_kernels)   // (the row-kernel path forms the finest level inside its pyramid launch)
         hipLaunchKernelGGL(vae::k_sigmoid_gather, dim3(blocks_for(n)), dim3(256), 0, e->stream, cae_internal::trunk_raw_output(e->trunk), e->ds[which].t, perm,
                            (long long)start, B, E, e->f(e->sx[0]), e->f(e->sy[0]));
-    double* ssum = reinterpret_cast<double*>(e->ws + e->off_ssum);
-    VHIP_TRY(hipMemsetAsync(ssum, 0, (size_t)vae::kScales * BC * 2 * sizeof(double), e->stream));
+    double* ssum = reinterpret_cast<double*>(e->ws + e->off_ssum);   // (cleared by step_common together with the loss parts)
     if (e->row_kernels) {
         // the pooling pyramid of both maps in one launch, the finest scale's walk, then the four coarse scales' walks in one launch
         vae::Pyramid pm;
@@ -150,10 +149,9 @@ int loss(vae_engine* e, int which, const int32_t* perm, int64_t start, int B, in
                                e->f(e->sC[s]));
         }
     }
-    int nv[vae::kScales];
-    for (int s = 0, hh = H, ww = W; s < vae::kScales; s++, hh /= 2, ww /= 2) nv[s] = (hh - vae::kHalo) * (ww - vae::kHalo);
-    VHIP_TRY(hipMemcpyAsync(e->f(e->nvalid), nv, sizeof nv, hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(vae::k_msssim_finalize, dim3(1), dim3(256), 0, e->stream, ssum, BC, reinterpret_cast<const int*>(e->f(e->nvalid)),
+    vae::ScaleCounts nv;
+    for (int s = 0, hh = H, ww = W; s < vae::kScales; s++, hh /= 2, ww /= 2) nv.v[s] = (hh - vae::kHalo) * (ww - vae::kHalo);
+    hipLaunchKernelGGL(vae::k_msssim_finalize, dim3(1), dim3(256), 0, e->stream, ssum, BC, nv,
                        (float)e->l_ssim, parts + 2, e->f(e->kappa));
     if (want_grad && e->row_kernels) {
         // the four coarse scales' own terms in one launch, their pooling chain folded into scale 1's map, then the finest scale
@@ -218,7 +216,8 @@ int step_common(vae_engine* e, int which, const int32_t* perm, int64_t start, in
     hipLaunchKernelGGL(k_gather, dim3(blocks_for((long long)batch * E)), dim3(256), 0, e->stream, e->ds[which].x, perm, (long long)start,
                        batch, E, e->f(e->xb));
     double* parts = e->parts();
-    VHIP_TRY(hipMemsetAsync(parts, 0, 4 * sizeof(double), e->stream));
+    // the MS-SSIM sums and the loss parts lie next to each other: one fill
+    VHIP_TRY(hipMemsetAsync(e->ws + e->off_ssum, 0, (size_t)(e->off_part + 4 * sizeof(double) - e->off_ssum), e->stream));
     // trunk forward: encoder stack, Linear + heads, z (call-back), decoder stack; the last layer leaves its raw output
     if ((rc = cae_internal::trunk_forward(e->trunk, e->f(e->xb), batch, train, true, nullptr))) return rc;
     // KL is a mean over B*latent
@@ -289,7 +288,7 @@ int vae_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spec
         const int64_t nv = BC * (h - vae::kHalo) * (w - vae::kHalo);
         e->sA[s] = F32(nv), e->sB[s] = F32(nv), e->sC[s] = F32(nv);
     }
-    e->kappa = F32(BC * vae::kScales), e->nvalid = F32(16);
+    e->kappa = F32(BC * vae::kScales);
     int64_t off = 0;
     auto bytes = [&](int64_t n) {
         const int64_t o = off;
