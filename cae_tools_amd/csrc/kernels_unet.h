@@ -923,31 +923,85 @@ struct Hyper {
     double lr, beta1, beta2, eps, wd;
 };
 
+// parameter ranges whose gradient was stored as fp32 (one writer per element, the whole sum in one store: the big Linear
+// layers, kernels_unet_lin.h) in the first half of their fp64 accumulator slots: element i of [lo, hi) is float number i - lo
+// counted from (float*)(gacc + lo).  Such a range is not cleared by its consumer: its producer overwrites it.
+struct F32Ranges {
+    long long lo[4], hi[4];
+    int n;
+};
+__device__ __forceinline__ bool f32_grad(const F32Ranges& fr, long long i, const double* gacc, float& g) {
+    for (int r = 0; r < fr.n; r++)
+        if (i >= fr.lo[r] && i < fr.hi[r]) {
+            g = reinterpret_cast<const float*>(gacc + fr.lo[r])[i - fr.lo[r]];
+            return true;
+        }
+    return false;
+}
+
+// step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t), decay = 1 - lr * wd: formed on the host in fp64 (the step number is
+// a host-side count here), so that no workgroup starts with two fp64 pow() calls in front of its loads
+struct AdamwConsts {
+    float step_size, bc2_sqrt, decay, b1, b2, eps;
+};
+__device__ __forceinline__ void adamw_one(float g, float& w, float& mi, float& vi, const AdamwConsts& c) {
+    w *= c.decay;
+    mi = mi + (g - mi) * (1.f - c.b1);              // exp_avg.lerp_(grad, 1 - beta1)
+    vi = fmaf(g * g, 1.f - c.b2, vi * c.b2);        // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(vi) / c.bc2_sqrt + c.eps;
+    w -= c.step_size * (mi / denom);
+}
+
+// four parameters per thread and trip (16-byte accesses; the arenas are 16-byte aligned); a group of four that straddles the
+// edge of an fp32 range takes the element-wise path.  grid: a few workgroups per CU, grid-stride
 __global__ void __launch_bounds__(256) k_adamw(long long n, float* __restrict__ p, double* __restrict__ gacc,
-                                               float* __restrict__ m, float* __restrict__ v, Hyper h, int step) {
-    __shared__ float corr[2];   // one lane per workgroup pays for the two fp64 pow() of the bias corrections
-    if (threadIdx.x == 0) {
-        const double bc1 = 1.0 - pow(h.beta1, (double)step);
-        const double bc2 = 1.0 - pow(h.beta2, (double)step);
-        corr[0] = (float)(h.lr / bc1);
-        corr[1] = (float)sqrt(bc2);
-    }
-    __syncthreads();
-    const float step_size = corr[0];
-    const float bc2_sqrt = corr[1];
-    const float decay = (float)(1.0 - h.lr * h.wd);
-    const float b1 = (float)h.beta1, b2 = (float)h.beta2, eps = (float)h.eps;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float g = (float)gacc[i];
-        gacc[i] = 0.0;
-        float w = p[i] * decay;
-        const float mi = m[i] + (g - m[i]) * (1.f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
-        const float vi = fmaf(g * g, 1.f - b2, v[i] * b2);        // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        w -= step_size * (mi / denom);
-        p[i] = w;
-        m[i] = mi;
-        v[i] = vi;
+                                               float* __restrict__ m, float* __restrict__ v, AdamwConsts c, F32Ranges fr) {
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; 4 * t < n; t += (long long)gridDim.x * 256) {
+        const long long i0 = 4 * t;
+        int r = -1;
+        bool whole = i0 + 3 < n;
+        for (int k = 0; k < fr.n; k++) {
+            const bool in0 = i0 >= fr.lo[k] && i0 < fr.hi[k], in3 = i0 + 3 >= fr.lo[k] && i0 + 3 < fr.hi[k];
+            if (in0 && in3) r = k;
+            else if (in0 || in3 || (fr.lo[k] > i0 && fr.lo[k] <= i0 + 3)) whole = false;
+        }
+        if (whole) {
+            float4 P = *reinterpret_cast<const float4*>(p + i0), M = *reinterpret_cast<const float4*>(m + i0);
+            float4 V = *reinterpret_cast<const float4*>(v + i0);
+            float g[4];
+            if (r >= 0) {
+                const float* gf = reinterpret_cast<const float*>(gacc + fr.lo[r]) + (i0 - fr.lo[r]);
+                if ((fr.lo[r] & 3) == 0) {
+                    const float4 G = *reinterpret_cast<const float4*>(gf);
+                    g[0] = G.x, g[1] = G.y, g[2] = G.z, g[3] = G.w;
+                } else {
+                    g[0] = gf[0], g[1] = gf[1], g[2] = gf[2], g[3] = gf[3];
+                }
+            } else {
+                double2* gd = reinterpret_cast<double2*>(gacc + i0);
+                const double2 a = gd[0], b = gd[1];
+                g[0] = (float)a.x, g[1] = (float)a.y, g[2] = (float)b.x, g[3] = (float)b.y;
+                gd[0] = make_double2(0.0, 0.0), gd[1] = make_double2(0.0, 0.0);
+            }
+            adamw_one(g[0], P.x, M.x, V.x, c);
+            adamw_one(g[1], P.y, M.y, V.y, c);
+            adamw_one(g[2], P.z, M.z, V.z, c);
+            adamw_one(g[3], P.w, M.w, V.w, c);
+            *reinterpret_cast<float4*>(p + i0) = P;
+            *reinterpret_cast<float4*>(m + i0) = M;
+            *reinterpret_cast<float4*>(v + i0) = V;
+            continue;
+        }
+        for (long long i = i0; i < i0 + 4 && i < n; i++) {
+            float g;
+            if (!f32_grad(fr, i, gacc, g)) {
+                g = (float)gacc[i];
+                gacc[i] = 0.0;
+            }
+            float w = p[i], mi = m[i], vi = v[i];
+            adamw_one(g, w, mi, vi, c);
+            p[i] = w, m[i] = mi, v[i] = vi;
+        }
     }
 }
 
@@ -956,9 +1010,11 @@ __global__ void __launch_bounds__(256) k_f32_to_acc(long long n, const float* __
 }
 
 __global__ void __launch_bounds__(256) k_acc_to_f32(long long n, const double* __restrict__ gacc, float* __restrict__ g32,
-                                                    double scale) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        g32[i] = (float)(gacc[i] * scale);
+                                                    double scale, F32Ranges fr) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float g;
+        g32[i] = f32_grad(fr, i, gacc, g) ? (float)((double)g * scale) : (float)(gacc[i] * scale);
+    }
 }
 
 }  // namespace

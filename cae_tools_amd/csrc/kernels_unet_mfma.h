@@ -129,16 +129,28 @@ struct OpDown {
     }
 };
 
-// weights repacked per parity: wp[z][cl][cs*4 + j*2 + i] = w[cs][cl][1-py+2j][1-px+2i],  z = py*2 + px
-__global__ void __launch_bounds__(256) k_pack_up_weights(int Cs, int Cl, const float* __restrict__ w, float* __restrict__ wp) {
-    const long long total = (long long)4 * Cl * Cs * 4;
-    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+// weights repacked per parity: wp[z][cl][cs*4 + j*2 + i] = w[cs][cl][1-py+2j][1-px+2i],  z = py*2 + px; every layer that runs
+// OpUp this step in one launch (the weights only change in the optimiser step): layer l owns elements [begin[l], begin[l+1])
+struct PackSet {
+    int n;
+    int Cs[8], Cl[8];
+    const float* w[8];
+    float* wp[8];
+    long long begin[9];
+};
+__global__ void __launch_bounds__(256) k_pack_up_weights(PackSet ps) {
+    const long long total = ps.begin[ps.n];
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        int l = 0;
+        while (l + 1 < ps.n && e >= ps.begin[l + 1]) l++;
+        const int Cs = ps.Cs[l], Cl = ps.Cl[l];
+        const long long o = e - ps.begin[l];
         const int k = (int)(o % (Cs * 4));
         const long long r = o / (Cs * 4);
         const int cl = (int)(r % Cl), z = (int)(r / Cl);
         const int cs = k >> 2, j = (k >> 1) & 1, i = k & 1;
         const int ky = 1 - (z >> 1) + 2 * j, kx = 1 - (z & 1) + 2 * i;
-        wp[o] = w[((size_t)cs * Cl + cl) * 16 + ky * 4 + kx];
+        ps.wp[l][o] = ps.w[l][((size_t)cs * Cl + cl) * 16 + ky * 4 + kx];
     }
 }
 
@@ -276,6 +288,13 @@ struct OpWgrad {
     __device__ long long col(long long m, int) const { return m < cols() ? m : -1; }
     __device__ void store(long long cb, int n, float v, int) const {
         if (n >= g.Cs || cb < 0 || v == 0.f) return;
+#if defined(IG_ABL) && IG_ABL == 4
+        if (v != 12345.678f) return;
+#endif
+#if defined(IG_ABL) && IG_ABL == 5
+        atomicAdd(reinterpret_cast<float*>(acc) + (size_t)n * g.Cl * 16 + cb, v);
+        return;
+#endif
         atomicAdd(&acc[(size_t)n * g.Cl * 16 + cb], (double)v);
     }
 };
@@ -390,10 +409,20 @@ __global__ void __launch_bounds__(256) k_igemm(Op op) {
 #pragma unroll
         for (int i = 0; i < NWQ; i++) {
             const int q = tid + NT * i;
+#if defined(IG_ABL) && (IG_ABL == 2 || IG_ABL >= 6)
+            wq[i] = make_float4((float)q, 1.f, 2.f, 3.f);
+#else
             wq[i] = (TN * 4 % NT == 0 || q < TN * 4) ? op.template wquad<TN>(ctx, kx, q, n0, kc, z) : make_float4(0, 0, 0, 0);
+#endif
         }
 #pragma unroll
-        for (int i = 0; i < NXQ; i++) xq[i] = op.template xquad<TM, NT>(ctx, kx, tid, i, m0, kc, z);
+        for (int i = 0; i < NXQ; i++) {
+#if defined(IG_ABL) && (IG_ABL == 1 || IG_ABL == 2 || IG_ABL >= 6)
+            xq[i] = make_float4((float)tid, (float)i, (float)kc, 1.f);
+#else
+            xq[i] = op.template xquad<TM, NT>(ctx, kx, tid, i, m0, kc, z);
+#endif
+        }
     };
     auto commit = [&](float* Wb) {
         float* Xb = Wb + TN * KS;
@@ -434,6 +463,11 @@ __global__ void __launch_bounds__(256) k_igemm(Op op) {
             float4 b4[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) b4[c] = ld4(Xb + brow + c * 32 * KS + ko);
+#if defined(IG_ABL) && IG_ABL == 3
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c][0] += a4.x * b4[c].x + a4.y * b4[c].y + a4.z * b4[c].z + a4.w * b4[c].w;
+            continue;
+#endif
 #pragma unroll
             for (int c = 0; c < 4; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[c].x, acc[c], 0, 0, 0);
 #pragma unroll
@@ -443,6 +477,14 @@ __global__ void __launch_bounds__(256) k_igemm(Op op) {
 #pragma unroll
             for (int c = 0; c < 4; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[c].w, acc[c], 0, 0, 0);
         }
+#if defined(IG_ABL) && IG_ABL == 6
+        continue;
+#endif
+#if defined(IG_ABL) && IG_ABL == 7
+        __syncthreads();
+        buf ^= 1;
+        continue;
+#endif
         if (more) commit(lds + (buf ^ 1) * BUF);
         __syncthreads();
         buf ^= 1;
@@ -519,13 +561,10 @@ inline void mfma_down_launch(const Geom& g, const float* L, const float* w, cons
     });
 }
 
-// scratch: Cs*Cl*16 floats for the repacked weights
-inline void mfma_up_launch(const Geom& g, const float* S, const float* w, const float* bias, float* L, float* scratch,
-                           hipStream_t s) {
-    const long long total = (long long)16 * g.Cl * g.Cs;
-    hipLaunchKernelGGL(k_pack_up_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g.Cs, g.Cl, w, scratch);
+// wp: the layer's weights repacked by k_pack_up_weights (Cs*Cl*16 floats)
+inline void mfma_up_launch(const Geom& g, const float* S, const float* wp, const float* bias, float* L, hipStream_t s) {
     igemm_dispatch<OpUp>(g.Cl, (long long)g.B * g.Hs * g.Ws, 4, s, [&](auto& op) {
-        op.g = g, op.S = S, op.wp = scratch, op.bias = bias, op.L = L;
+        op.g = g, op.S = S, op.wp = wp, op.bias = bias, op.L = L;
     });
 }
 

@@ -112,7 +112,7 @@ int step_common(lin_engine* e, int which, const int32_t* perm, int64_t start, in
                            e->gacc() + e->nout * e->nin);
         if (grads_out)
             hipLaunchKernelGGL(k_acc_to_f32, dim3(blocks_for(e->n_params)), dim3(256), 0, e->stream, (long long)e->n_params, e->gacc(),
-                               grads_out, grad_scale);
+                               grads_out, grad_scale, F32Ranges{{0, 0, 0, 0}, {0, 0, 0, 0}, 0});
         if (optimise) {
             e->step += 1;
             hipLaunchKernelGGL(vae::k_adam_l2, dim3(blocks_for(e->n_params)), dim3(256), 0, e->stream, (long long)e->n_params, e->params,

@@ -15,7 +15,7 @@
 #include "cae_unet.h"
 #include "kernels_unet.h"
 #include "kernels_unet_mfma.h"
-#include "kernels_unet_skinny.h"
+#include "kernels_unet_lin.h"
 
 // The ConvAE path's 16x16-tile MFMA GEMM (kernels_gemm.h: four waves split K, one launch for a Linear layer's weight gradient
 // beside its input gradient) for the SMALL Linear layers here (fc -> latent -> fc): the convolution tile engine's strided
@@ -68,6 +68,7 @@ struct Bn {
 struct ConvLayer {
     Geom g;                          // B filled per call
     int64_t w = 0, b = 0;            // parameter arena
+    int64_t wp = -1;                 // workspace: weights repacked per output parity (layers that run OpUp), or -1
     bool has_bn = false, has_skip = false;
     Bn bn;
     int R = 0;                       // attention hidden width
@@ -108,7 +109,10 @@ struct unet_engine {
     // workspace
     int64_t ws_bytes = 0;
     int64_t off_gacc = 0, off_dsum = 0, n_dsum = 0, off_losses = 0, off_ls = 0, off_f32 = 0, off_gscratch = 0, gscratch_bytes = 0;
-    int64_t xb = 0, y = 0, coef = 0, scratch = 0;
+    int64_t off_linpart = 0, linpart_bytes = 0;   // K-slice partial tiles of the big Linear layers (kernels_unet_lin.h)
+    bool fc_f32[4] = {false, false, false, false};   // this backward stored fc[k]'s weight gradient as fp32 (F32Ranges)
+    bool fc_f32_dirty[4] = {false, false, false, false};   // ... and nothing has cleared those accumulator slots since
+    int64_t xb = 0, y = 0, coef = 0;
     char* ws = nullptr;
     float *params = nullptr, *m = nullptr, *v = nullptr, *buffers = nullptr;
     hipStream_t stream = nullptr;
@@ -117,7 +121,7 @@ struct unet_engine {
     uint32_t seed = 0;
     int64_t step = 0;
     int specialised = 1;
-    bool gacc_clean = false;   // the fp64 gradient accumulator is all zero (k_adamw clears what it consumes)
+    bool gacc_clean = false;   // the fp64 gradient accumulator is all zero (k_adamw clears what it consumes) but for fc_f32_dirty
     DataSet ds[2];
 
     float* f(int64_t off) const { return reinterpret_cast<float*>(ws + off_f32) + off; }
@@ -186,7 +190,8 @@ void conv_down(unet_engine* e, const Geom& g, const float* L, const float* w, co
     hipLaunchKernelGGL(k_down, dim3(blocks_for(total, 65536)), dim3(256), 0, e->stream, g, L, w, bias, S);
 }
 
-void conv_up(unet_engine* e, const Geom& g, const float* S, const float* w, const float* bias, float* L) {
+// wp: the layer's repacked weights (pack_up_weights below) or nullptr when the layer does not run the tile engine
+void conv_up(unet_engine* e, const Geom& g, const float* S, const float* w, const float* wp, const float* bias, float* L) {
     if (e->specialised && mfma_geom(g) && g.Cl <= 4) {   // a handful of output channels: streaming kernel, not a GEMM
         const int blocks = blocks_for((long long)g.B * g.Hs * g.Ws, 65536);
         switch (g.Cl) {
@@ -197,8 +202,8 @@ void conv_up(unet_engine* e, const Geom& g, const float* S, const float* w, cons
         }
         return;
     }
-    if (e->specialised && mfma_up_eligible(g)) {
-        mfma_up_launch(g, S, w, bias, L, e->f(e->scratch), e->stream);
+    if (e->specialised && wp && mfma_up_eligible(g)) {
+        mfma_up_launch(g, S, wp, bias, L, e->stream);
         return;
     }
     const long long total = (long long)g.B * g.Cl * g.Hl * g.Wl;
@@ -269,7 +274,43 @@ ugemm::cae::GemmArgs gemm16_args(int M, int N, int K) {
     return g;
 }
 
+// the big layers on kernels_unet_lin.h: batch <= 64, 16-byte rows, room for the K slices' partial tiles
+bool lin_big(const unet_engine* e, const Fc& L, int B) {
+    if (!e->specialised || small_fc(L) || B > 64 || (L.nin & 3) || (L.nout & 3)) return false;
+    static const int off = getenv("CAE_UNET_LIN") ? atoi(getenv("CAE_UNET_LIN")) == 0 : 0;   // env: A/B measurements only
+    if (off) return false;
+    const long long need = (long long)std::max((L.nin + 127) / 128 * (long long)L.nout, (L.nout + 127) / 128 * (long long)L.nin) * B * 4;
+    return need <= e->linpart_bytes;
+}
+
+// Y[b][n] = bias[n] + sum_k X[b][k] W[..]: nt = W[n][k] (forward), else W[k][n] (input gradient)
+void lin_gemm(unet_engine* e, bool nt, const float* X, long long x_ld, const float* W, long long w_ld, const float* bias, float* Y,
+              int B, int N, int K) {
+    LinArgs a;
+    a.X = X, a.x_ld = x_ld, a.W = W, a.w_ld = w_ld, a.bias = bias, a.Y = Y, a.y_ld = N, a.B = B, a.N = N, a.K = K, a.kiters = 2;
+    const int slices = (K + a.kiters * kLinKT - 1) / (a.kiters * kLinKT);
+    a.part = slices > 1 ? reinterpret_cast<float*>(e->ws + e->off_linpart) : nullptr;
+    const dim3 grid((N + kLinNT - 1) / kLinNT, slices);
+    const int RB = B > 32 ? 2 : 1;
+    if (nt) {
+        const size_t lds = (size_t)(32 * RB + 128) * kLinPK * sizeof(float);
+        if (RB == 1) hipLaunchKernelGGL(k_lin_nt<1>, grid, dim3(256), lds, e->stream, a);
+        else hipLaunchKernelGGL(k_lin_nt<2>, grid, dim3(256), lds, e->stream, a);
+    } else {
+        const size_t lds = (size_t)(32 * RB * kLinPK + kLinKT * kLinPN) * sizeof(float);
+        if (RB == 1) hipLaunchKernelGGL(k_lin_nn<1>, grid, dim3(256), lds, e->stream, a);
+        else hipLaunchKernelGGL(k_lin_nn<2>, grid, dim3(256), lds, e->stream, a);
+    }
+    if (slices > 1)
+        hipLaunchKernelGGL(k_lin_fold, dim3((unsigned)(((long long)B * N + 15) / 16)), dim3(256), 0, e->stream, a.part, slices, B, N, bias,
+                           Y, (long long)N);
+}
+
 void lin_fwd(unet_engine* e, const Fc& L, int B, const float* in, float* out) {
+    if (lin_big(e, L, B)) {   // out[b][o] = bias[o] + sum_i in[b][i] W[o][i]
+        lin_gemm(e, true, in, L.nin, e->P(L.w), L.nin, e->P(L.b), out, B, L.nout, L.nin);
+        return;
+    }
     if (e->specialised && small_fc(L)) {   // out[b][o] = bias[o] + sum_i in[b][i] W[o][i]
         ugemm::cae::GemmArgs ga = gemm16_args(B, L.nout, L.nin);
         ga.A = in, ga.sa_m = L.nin, ga.sa_k = 1;
@@ -291,6 +332,29 @@ void lin_fwd(unet_engine* e, const Fc& L, int B, const float* in, float* out) {
 }
 
 void lin_bwd(unet_engine* e, const Fc& L, int B, const float* in, const float* gout, float* gin) {
+    const int fk = (int)(&L - e->fc);
+    const bool big = lin_big(e, L, B);
+    if (!big && e->fc_f32_dirty[fk]) {   // an earlier step left fp32 gradients in these fp64 slots
+        (void)hipMemsetAsync(e->gacc(L.w), 0, (size_t)L.nin * L.nout * sizeof(double), e->stream);
+        e->fc_f32_dirty[fk] = false;
+    }
+    e->fc_f32[fk] = big;
+    if (big) {
+        // dW[o][i] = sum_b gout[b][o] in[b][i] as fp32 in the first half of the weight's accumulator slots (F32Ranges),
+        // db[o] = sum_b gout[b][o];  gin[b][i] = sum_o gout[b][o] W[o][i]
+        e->fc_f32_dirty[fk] = true;
+        const int B8 = (B + 7) & ~7;
+        const size_t lds = (size_t)2 * B8 * kLinPN * sizeof(float);
+        static bool raised = false;   // above the 64 KiB a kernel gets without asking (batch > 56)
+        if (lds > 65536 && !raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lin_outer), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * kLinPN * 4);
+            raised = true;
+        }
+        hipLaunchKernelGGL(k_lin_outer, dim3((L.nin + 127) / 128, (L.nout + 127) / 128), dim3(256), lds, e->stream, gout, (long long)L.nout, in,
+                           (long long)L.nin, B, L.nout, L.nin, reinterpret_cast<float*>(e->gacc(L.w)), e->gacc(L.b));
+        if (gin) lin_gemm(e, false, gout, L.nout, e->P(L.w), L.nin, nullptr, gin, B, L.nin, L.nout);
+        return;
+    }
     if (e->specialised && small_fc(L)) {
         // dW[o][i] = sum_b gout[b][o] in[b][i], db[o] = sum_b gout[b][o] (a ones column), K = the whole batch in one tile: plain
         // fp64 stores into the (zeroed) accumulator, one writer per element; beside it gin[b][i] = sum_o gout[b][o] W[o][i]
@@ -313,40 +377,6 @@ void lin_bwd(unet_engine* e, const Fc& L, int B, const float* in, const float* g
         hipLaunchKernelGGL(ugemm::cae::k_gemm16_pair, dim3(tiles_w + tiles_d), dim3(256), gemm16_lds(), e->stream, gw, gd, tiles_w, 0);
         return;
     }
-    if (e->specialised && B <= 64) {
-        // the big layers (kernels_unet_skinny.h): the weight gradient as 64x64 output tiles with plain fp64 stores (the
-        // accumulator is zero here and every element has one writer), the input gradient as one pass over W[o][i] rows with
-        // the o range sliced over workgroups and the slices' partial tiles folded in order
-        hipLaunchKernelGGL(k_skinny_outer, dim3((L.nin + 63) / 64, (L.nout + 63) / 64), dim3(256), (size_t)2 * B * 68 * sizeof(float), e->stream, gout, in, B, L.nout,
-                           L.nin, e->gacc(L.w), e->gacc(L.b));
-        if (gin) {
-            const int slices = (L.nout + kSkKs - 1) / kSkKs;
-            static const int wide_env = getenv("CAE_SKINNY_WIDE") ? atoi(getenv("CAE_SKINNY_WIDE")) : 1;   // env: A/B measurements only
-            const bool wide = L.nin >= 256 && wide_env != 0;      // 8 rows x 4 columns per thread, else 4 x 4
-            const int bt = wide ? 8 : 4;
-            int bgs = 1;
-            while (bgs * bt < B) bgs *= 2;
-            const int cols = 4 * (256 / bgs);
-            float* part = nullptr;
-            if (slices > 1) {
-                const long long need = (long long)slices * B * L.nin * (long long)sizeof(float);
-                if (need <= e->gscratch_bytes) part = reinterpret_cast<float*>(e->ws + e->off_gscratch);
-            }
-            if (slices == 1 || part) {
-                const dim3 grid((L.nin + cols - 1) / cols, slices);
-                if (wide) hipLaunchKernelGGL(k_skinny_kj<8>, grid, dim3(256), 0, e->stream, gout, (long long)L.nout, e->P(L.w), B, L.nout, L.nin, bgs, gin, part);
-                else hipLaunchKernelGGL(k_skinny_kj<4>, grid, dim3(256), 0, e->stream, gout, (long long)L.nout, e->P(L.w), B, L.nout, L.nin, bgs, gin, part);
-                if (part) {
-                    const long long n = (long long)B * L.nin;
-                    hipLaunchKernelGGL(k_skinny_fold, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, e->stream, part, slices, n, gin);
-                }
-            } else {
-                GemmDesc d{L.nin, B, L.nout, e->P(L.w), 1, L.nin, gout, 1, L.nout, nullptr, gin, nullptr, 1, L.nin, 0};
-                gemm_launch(d, reinterpret_cast<double*>(e->ws + e->off_gscratch), e->stream);
-            }
-        }
-        return;
-    }
     if (e->specialised) {
         // dW[o][i] += sum_b gout[b][o] in[b][i];  db[o] += sum_b gout[b][o];  gin[b][i] = sum_o gout[b][o] W[o][i]
         GemmDesc w{L.nout, L.nin, B, gout, 1, L.nout, in, L.nin, 1, nullptr, nullptr, e->gacc(L.w), L.nin, 1, 2};
@@ -365,11 +395,29 @@ void lin_bwd(unet_engine* e, const Fc& L, int B, const float* in, const float* g
                            L.nout, gout, e->P(L.w), gin);
 }
 
+// the weights of every layer that runs OpUp (decoder forward; encoder input gradients when training), repacked in one launch
+void pack_up_weights(unet_engine* e, bool train) {
+    if (!e->specialised) return;
+    PackSet ps;
+    memset(&ps, 0, sizeof ps);
+    auto add = [&](const ConvLayer& L) {
+        if (L.wp < 0 || ps.n == 8) return;
+        ps.Cs[ps.n] = L.g.Cs, ps.Cl[ps.n] = L.g.Cl, ps.w[ps.n] = e->P(L.w), ps.wp[ps.n] = e->f(L.wp);
+        ps.begin[ps.n + 1] = ps.begin[ps.n] + (long long)16 * L.g.Cs * L.g.Cl;
+        ps.n++;
+    };
+    for (auto& L : e->dec) add(L);
+    if (train)
+        for (size_t i = 1; i < e->enc.size(); i++) add(e->enc[i]);
+    if (ps.n) hipLaunchKernelGGL(k_pack_up_weights, dim3(blocks_for(ps.begin[ps.n], 2048)), dim3(256), 0, e->stream, ps);
+}
+
 // ---- forward ----------------------------------------------------------------------------------------
 // x: (B, in_c, in_h, in_w) contiguous.  Leaves the raw last-layer output in dec.back().u
 int forward(unet_engine* e, const float* x, int B, bool train) {
     const int n = (int)e->enc.size();
     if (train) UHIP_TRY(hipMemsetAsync(e->dsum(0), 0, (size_t)e->n_dsum * sizeof(double), e->stream));
+    pack_up_weights(e, train);
     const float* cur = x;
     for (int i = 0; i < n; i++) {
         ConvLayer& L = e->enc[i];
@@ -404,7 +452,7 @@ int forward(unet_engine* e, const float* x, int B, bool train) {
         Geom g = L.g;
         g.B = B;
         const int HW = g.Hl * g.Wl, C = g.Cl;
-        conv_up(e, g, cur, e->P(L.w), e->P(L.b), e->f(L.u));
+        conv_up(e, g, cur, e->P(L.w), L.wp >= 0 ? e->f(L.wp) : nullptr, e->P(L.b), e->f(L.u));
         if (!L.has_bn) break;   // last layer: sigmoid is applied by the loss / score kernels
         const float* skip = e->f(e->enc[n - 2 - j].s);
         hipLaunchKernelGGL(k_pool, dim3(B * C), dim3(256), 0, e->stream, e->f(L.u), HW, e->f(L.pool));
@@ -453,7 +501,10 @@ int loss_forward(unet_engine* e, int which, const int32_t* perm, int64_t start, 
 // ---- backward ---------------------------------------------------------------------------------------
 int backward(unet_engine* e, const float* x, int B) {
     const int n = (int)e->enc.size(), nd = (int)e->dec.size();
-    if (!e->gacc_clean) UHIP_TRY(hipMemsetAsync(e->gacc(0), 0, (size_t)e->n_params * sizeof(double), e->stream));
+    if (!e->gacc_clean) {
+        UHIP_TRY(hipMemsetAsync(e->gacc(0), 0, (size_t)e->n_params * sizeof(double), e->stream));
+        for (int k = 0; k < 4; k++) e->fc_f32_dirty[k] = false;
+    }
     e->gacc_clean = false;
     for (int j = nd - 1; j >= 0; j--) {
         ConvLayer& L = e->dec[j];
@@ -521,7 +572,7 @@ int backward(unet_engine* e, const float* x, int B) {
         // no bias gradient: this bias is added right before a BatchNorm, whose backward makes every channel of dz sum
         // to zero (the reference's autograd returns rounding noise of ~1e-8 here)
         if (i > 0) {
-            conv_up(e, g, e->f(L.gz), e->P(L.w), nullptr, e->f(e->enc[i - 1].ga));
+            conv_up(e, g, e->f(L.gz), e->P(L.w), L.wp >= 0 ? e->f(L.wp) : nullptr, nullptr, e->f(e->enc[i - 1].ga));
             gin = e->f(e->enc[i - 1].ga);
         }
     }
@@ -549,6 +600,21 @@ int gather_x(unet_engine* e, int which, const int32_t* perm, int64_t start, int 
     return CAE_OK;
 }
 
+AdamwConsts adamw_consts(const unet_engine* e) {
+    const Hyper& h = e->hyper;
+    const double bc1 = 1.0 - pow(h.beta1, (double)e->step), bc2 = 1.0 - pow(h.beta2, (double)e->step);
+    return AdamwConsts{(float)(h.lr / bc1), (float)sqrt(bc2), (float)(1.0 - h.lr * h.wd), (float)h.beta1, (float)h.beta2, (float)h.eps};
+}
+int adamw_blocks(const unet_engine* e) { return blocks_for((e->n_params + 3) / 4, 2048); }
+
+F32Ranges f32_ranges(const unet_engine* e) {
+    F32Ranges fr;
+    memset(&fr, 0, sizeof fr);
+    for (int k = 0; k < 4; k++)
+        if (e->fc_f32[k]) fr.lo[fr.n] = e->fc[k].w, fr.hi[fr.n] = e->fc[k].w + (long long)e->fc[k].nin * e->fc[k].nout, fr.n++;
+    return fr;
+}
+
 int train_or_fb(unet_engine* e, int which, const int32_t* perm, int64_t start, int batch, int slot, float* grads_out,
                 double grad_scale = 1.0) {
     int rc = check_batch(e, which, perm, start, batch, slot);
@@ -559,11 +625,11 @@ int train_or_fb(unet_engine* e, int which, const int32_t* perm, int64_t start, i
     if ((rc = backward(e, e->f(e->xb), batch))) return rc;
     if (grads_out) {
         hipLaunchKernelGGL(k_acc_to_f32, dim3(blocks_for(e->n_params, 65536)), dim3(256), 0, e->stream, (long long)e->n_params,
-                           e->gacc(0), grads_out, grad_scale);
+                           e->gacc(0), grads_out, grad_scale, f32_ranges(e));
     } else {
         e->step += 1;
-        hipLaunchKernelGGL(k_adamw, dim3(blocks_for(e->n_params, 65536)), dim3(256), 0, e->stream, (long long)e->n_params,
-                           e->params, e->gacc(0), e->m, e->v, e->hyper, (int)e->step);
+        hipLaunchKernelGGL(k_adamw, dim3(adamw_blocks(e)), dim3(256), 0, e->stream, (long long)e->n_params, e->params, e->gacc(0), e->m,
+                           e->v, adamw_consts(e), f32_ranges(e));
         e->gacc_clean = true;
     }
     UHIP_TRY(hipGetLastError());
@@ -712,10 +778,14 @@ int unet_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spe
         }
     }
     e->coef = F32(4 * B * e->out_c);
-    int64_t wmax = 0;
-    for (auto& L : e->enc) wmax = std::max<int64_t>(wmax, (int64_t)L.g.Cs * L.g.Cl * L.g.kh * L.g.kw);
-    for (auto& L : e->dec) wmax = std::max<int64_t>(wmax, (int64_t)L.g.Cs * L.g.Cl * L.g.kh * L.g.kw);
-    e->scratch = F32(wmax);   // repacked weights of the layer being launched (kernels_unet_mfma.h)
+    // weights repacked per output parity for the layers that run OpUp (kernels_unet_mfma.h): decoder forward, encoder dgrad
+    auto carve_packed = [&](ConvLayer& L) {
+        Geom g = L.g;
+        g.B = (int)B;
+        if (mfma_up_eligible(g) && g.Cl > 4) L.wp = F32((int64_t)16 * g.Cs * g.Cl);
+    };
+    for (auto& L : e->dec) carve_packed(L);
+    for (size_t i = 1; i < e->enc.size(); i++) carve_packed(e->enc[i]);
     int64_t off = 0;
     auto bytes = [&](int64_t n) {
         const int64_t o = off;
@@ -730,6 +800,14 @@ int unet_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spe
     for (int k = 0; k < 4; k++) gs = std::max<int64_t>(gs, (int64_t)std::max(e->fc[k].nin, e->fc[k].nout) * B);
     e->off_gscratch = bytes(gs * 8);
     e->gscratch_bytes = gs * 8;
+    int64_t lp = 0;   // partial tiles of the big layers' K slices (128 wide), batch <= 64
+    for (int k = 0; k < 4; k++) {
+        const Fc& L = e->fc[k];
+        if (small_fc(L)) continue;
+        lp = std::max<int64_t>(lp, std::max<int64_t>((L.nin + 127) / 128 * (int64_t)L.nout, (L.nout + 127) / 128 * (int64_t)L.nin) * std::min<int64_t>(B, 64) * 4);
+    }
+    e->off_linpart = bytes(lp);
+    e->linpart_bytes = lp;
     e->off_f32 = bytes(nf * 4);
     e->ws_bytes = off;
     *out = e;
@@ -812,9 +890,10 @@ int unet_apply_gradients(unet_engine* e, const float* grads) {
     hipLaunchKernelGGL(k_f32_to_acc, dim3(blocks_for(e->n_params, 65536)), dim3(256), 0, e->stream, (long long)e->n_params, grads,
                        e->gacc(0));
     e->step += 1;
-    hipLaunchKernelGGL(k_adamw, dim3(blocks_for(e->n_params, 65536)), dim3(256), 0, e->stream, (long long)e->n_params, e->params,
-                       e->gacc(0), e->m, e->v, e->hyper, (int)e->step);
+    hipLaunchKernelGGL(k_adamw, dim3(adamw_blocks(e)), dim3(256), 0, e->stream, (long long)e->n_params, e->params, e->gacc(0), e->m,
+                       e->v, adamw_consts(e), F32Ranges{{0, 0, 0, 0}, {0, 0, 0, 0}, 0});
     e->gacc_clean = true;
+    for (int k = 0; k < 4; k++) e->fc_f32[k] = e->fc_f32_dirty[k] = false;   // every slot was rewritten as fp64 and cleared
     UHIP_TRY(hipGetLastError());
     return CAE_OK;
 }
