@@ -398,6 +398,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const float* __restrict__
     const int c = blockIdx.y;
     const float mean = saved[2 * c], invstd = saved[2 * c + 1];
     const float ga = gamma[c], be = beta[c];
+    const float sc = invstd * ga;
     double s1 = 0, s2 = 0;
     auto body = [&](auto VT) {
         constexpr int V = decltype(VT)::value;
@@ -414,7 +415,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const float* __restrict__
                 float gv = 0.f;
                 if (gA) gv = ta.v[j] * drop_factor(d, o + j);
                 if (gB) gv += tb.v[j];
-                if (!(fmaf(xh, ga, be) > 0.f)) gv = 0.f;
+                if (!(fmaf(zt.v[j] - mean, sc, be) > 0.f)) gv = 0.f;      // the forward's own expression: the same decision, bit for bit
                 g.v[j] = gv;
                 s1 += (double)gv;
                 s2 += (double)gv * (double)xh;
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply2(const float* __restrict__
     const int c = blockIdx.y;
     const float mean = saved[2 * c], invstd = saved[2 * c + 1];
     const float ga = gamma[c], be = beta[c];
-    const float k1 = ga * invstd;
+    const float k1 = ga * invstd, sc = invstd * ga;
     const float m1 = (float)(sums[2 * c] / N), m2 = (float)(sums[2 * c + 1] / N);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         acc_gamma[c] += sums[2 * c + 1];
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply2(const float* __restrict__
                 float gv = 0.f;
                 if (gA) gv = ta.v[j] * drop_factor(d, o + j);
                 if (gB) gv += tb.v[j];
-                if (!(fmaf(xh, ga, be) > 0.f)) gv = 0.f;
+                if (!(fmaf(zt.v[j] - mean, sc, be) > 0.f)) gv = 0.f;      // the forward's own expression: the same decision, bit for bit
                 g.v[j] = k1 * (gv - m1 - xh * m2);
             }
             g.st(dz + o);

@@ -16,6 +16,7 @@
 #include "kernels_unet.h"
 #include "kernels_unet_mfma.h"
 #include "kernels_unet_lin.h"
+#include "kernels_unet_thin.h"
 
 // The ConvAE path's 16x16-tile MFMA GEMM (kernels_gemm.h: four waves split K, one launch for a Linear layer's weight gradient
 // beside its input gradient) for the SMALL Linear layers here (fc -> latent -> fc): the convolution tile engine's strided
@@ -109,6 +110,7 @@ struct unet_engine {
     // workspace
     int64_t ws_bytes = 0;
     int64_t off_gacc = 0, off_dsum = 0, n_dsum = 0, off_losses = 0, off_ls = 0, off_f32 = 0, off_gscratch = 0, gscratch_bytes = 0;
+    int64_t off_thinpart = 0, thinpart_bytes = 0;   // per-workgroup weight-gradient tiles of the image-end layers (kernels_unet_thin.h)
     int64_t off_linpart = 0, linpart_bytes = 0;   // K-slice partial tiles of the big Linear layers (kernels_unet_lin.h)
     bool fc_f32[4] = {false, false, false, false};   // this backward stored fc[k]'s weight gradient as fp32 (F32Ranges)
     bool fc_f32_dirty[4] = {false, false, false, false};   // ... and nothing has cleared those accumulator slots since
@@ -182,6 +184,11 @@ Drop make_drop(const unet_engine* e, uint32_t site, bool train) {
 
 // ---- conv dispatch --------------------------------------------------------------------------------
 void conv_down(unet_engine* e, const Geom& g, const float* L, const float* w, const float* bias, float* S) {
+    static const int thin_off = getenv("CAE_UNET_THIN") ? atoi(getenv("CAE_UNET_THIN")) == 0 : 0;   // env: A/B measurements only
+    if (e->specialised && !thin_off && thin_geom(g)) {   // the image-end layers: kernels_unet_thin.h
+        thin_down_launch(g, L, w, bias, S, e->stream);
+        return;
+    }
     if (e->specialised && mfma_down_eligible(g)) {
         mfma_down_launch(g, L, w, bias, S, e->stream);
         return;
@@ -211,6 +218,12 @@ void conv_up(unet_engine* e, const Geom& g, const float* S, const float* w, cons
 }
 
 void conv_wgrad(unet_engine* e, const Geom& g, const float* S, const float* L, double* acc) {
+    static const int thin_off = getenv("CAE_UNET_THIN") ? atoi(getenv("CAE_UNET_THIN")) == 0 : 0;   // env: A/B measurements only
+    if (e->specialised && !thin_off && thin_geom(g)) {   // the image-end layers: kernels_unet_thin.h
+        float* part = thin_wgrad_part_bytes(g) <= (size_t)e->thinpart_bytes ? reinterpret_cast<float*>(e->ws + e->off_thinpart) : nullptr;
+        thin_wgrad_launch(g, S, L, acc, part, e->stream);
+        return;
+    }
     if (e->specialised && mfma_wgrad_eligible(g)) {
         mfma_wgrad_launch(g, S, L, acc, e->stream);
         return;
@@ -808,6 +821,16 @@ int unet_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spe
     }
     e->off_linpart = bytes(lp);
     e->linpart_bytes = lp;
+    int64_t tp = 0;
+    auto thin_need = [&](const ConvLayer& L) {
+        Geom g = L.g;
+        g.B = (int)B;
+        if (thin_geom(g)) tp = std::max<int64_t>(tp, (int64_t)thin_wgrad_part_bytes(g));
+    };
+    for (auto& L : e->enc) thin_need(L);
+    for (auto& L : e->dec) thin_need(L);
+    e->off_thinpart = bytes(tp);
+    e->thinpart_bytes = tp;
     e->off_f32 = bytes(nf * 4);
     e->ws_bytes = off;
     *out = e;

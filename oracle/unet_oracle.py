@@ -76,6 +76,50 @@ class Dropper:
         return x * (keep.to(x.dtype) * (1.0 / (1.0 - self.p)))
 
 
+# ReLU decisions.  An fp32 implementation that sums in another order can land a BatchNorm output on the other side of zero
+# where the exact value is within rounding of it; the element's whole upstream gradient then switches on or off, and one
+# such element moves a layer's weight gradient by percents.  A parity test can hand the oracle the decisions the
+# implementation under test took (`ReluAlign`): they are followed only where the oracle's own pre-activation is within
+# `tol` of zero, so a wrong decision anywhere else still shows.
+_relu_hook = None
+
+
+class ReluAlign:
+    """`decisions[name]`: boolean array (output > 0) per ReLU site — 'enc{i}', 'efc0', 'efc1', 'dfc0', 'dfc1', 'dec{j}'.
+    Taken from outputs AFTER a dropout, a False may also mean 'dropped': harmless, the element is zero either way."""
+
+    def __init__(self, decisions, tol=1e-5):
+        self.decisions, self.tol, self.followed = decisions, float(tol), {}
+        self.disagree = {}      # per site: (elements decided differently, the largest |pre-activation| among them)
+
+    def __call__(self, name, x):
+        own = x > 0
+        want = self.decisions.get(name)
+        if want is None:
+            return F.relu(x)
+        want = torch.as_tensor(np.asarray(want)).reshape(x.shape)
+        diff = own != want
+        if name.startswith(("enc", "efc")) or not bool(diff.any()):      # (sites read before their dropout: exact)
+            self.disagree[name] = (int(diff.sum()), float(x.detach().abs()[diff].max()) if bool(diff.any()) else 0.0)
+        follow = diff & (x.detach().abs() < self.tol)
+        self.followed[name] = self.followed.get(name, 0) + int(follow.sum())
+        return x * torch.where(follow, want, own).to(x.dtype)
+
+    def __enter__(self):
+        global _relu_hook
+        _relu_hook = self
+        return self
+
+    def __exit__(self, *exc):
+        global _relu_hook
+        _relu_hook = None
+        return False
+
+
+def _relu(x, name):
+    return F.relu(x) if _relu_hook is None else _relu_hook(name, x)
+
+
 def _bn(x, st, key, train):
     y = F.batch_norm(x, st[key + ".running_mean"], st[key + ".running_var"], st[key + ".weight"], st[key + ".bias"],
                      training=train, momentum=BN_MOMENTUM, eps=BN_EPS)
@@ -93,13 +137,13 @@ def encoder_forward(spec, enc, x, train, drop):
     for i, l in enumerate(spec["input_layers"]):
         c, b = f"encoder_cnn.{4 * i}", f"encoder_cnn.{4 * i + 1}"
         h = F.conv2d(h, enc[c + ".weight"], enc[c + ".bias"], stride=int(l["stride"]), padding=int(l["output_padding"]))
-        h = F.relu(_bn(h, enc, b, train))
+        h = _relu(_bn(h, enc, b, train), f"enc{i}")
         skips.append(h)
         h = drop(h, SITE_ENC_CONV + i)
     h = h.flatten(1)
     h = F.linear(h, enc["encoder_lin.0.weight"], enc["encoder_lin.0.bias"])
-    h = drop(F.relu(_bn(h, enc, "encoder_lin.1", train)), SITE_ENC_FC0)
-    h = drop(F.relu(F.linear(h, enc["encoder_lin.4.weight"], enc["encoder_lin.4.bias"])), SITE_ENC_FC1)
+    h = drop(_relu(_bn(h, enc, "encoder_lin.1", train), "efc0"), SITE_ENC_FC0)
+    h = drop(_relu(F.linear(h, enc["encoder_lin.4.weight"], enc["encoder_lin.4.bias"]), "efc1"), SITE_ENC_FC1)
     skips.pop()
     return h, skips
 
@@ -120,8 +164,8 @@ def decoder_forward(spec, dec, z, skips, train, drop):
     layers = spec["output_layers"]
     (c0, y0, x0) = layers[0]["input_dimensions"]
     h = F.linear(z, dec["decoder_lin.0.weight"], dec["decoder_lin.0.bias"])
-    h = drop(F.relu(_bn(h, dec, "decoder_lin.1", train)), SITE_DEC_FC0)
-    h = drop(F.relu(F.linear(h, dec["decoder_lin.4.weight"], dec["decoder_lin.4.bias"])), SITE_DEC_FC1)
+    h = drop(_relu(_bn(h, dec, "decoder_lin.1", train), "dfc0"), SITE_DEC_FC0)
+    h = drop(_relu(F.linear(h, dec["decoder_lin.4.weight"], dec["decoder_lin.4.bias"]), "dfc1"), SITE_DEC_FC1)
     h = h.view(h.shape[0], c0, y0, x0)
     rev = skips[::-1]
     for j, l in enumerate(layers):
@@ -132,7 +176,7 @@ def decoder_forward(spec, dec, z, skips, train, drop):
             h = h * channel_attention(dec, j, h)
             h = torch.cat((h, rev[j]), 1)
         if j != len(layers) - 1:
-            h = drop(F.relu(_bn(h, dec, b, train)), SITE_DEC_CONV + j)
+            h = drop(_relu(_bn(h, dec, b, train), f"dec{j}"), SITE_DEC_CONV + j)
     return torch.sigmoid(h)
 
 

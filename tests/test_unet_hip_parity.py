@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from unet_helpers import TRAIN_CASES, UNET_CASES, UnetCase, unet_oracle
+from unet_helpers import hip_relu_decisions, TRAIN_CASES, UNET_CASES, UnetCase, unet_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -193,17 +193,7 @@ def test_mfma_path_at_medium_size_against_oracle_and_generic_kernels():
     x = torch.rand((B, 3, 64, 64), generator=g)
     t = torch.rand((B, 3, 64, 64), generator=g)
     m = (torch.rand((B, 1, 64, 64), generator=g) < 0.85).float()
-    o = uo.UnetOracle(spec.save(), enc.state_dict(), dec.state_dict(), dropout_rate=0.1, seed=4)
-    o.step_count = 2
-    (mse, pl, _) = o.loss_and_grads(x, t, m)
-    want = o.grads()
-    # the same in fp64: how far the fp32 oracle itself is from the exact gradient on this model (BatchNorm over FIVE rows
-    # behind the first Linear layer makes the Linear section ill-conditioned: 2e-2 of a tensor's maximum is rounding here)
     to64 = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-    o64 = uo.UnetOracle(spec.save(), to64(enc.state_dict()), to64(dec.state_dict()), dropout_rate=0.1, seed=4)
-    o64.step_count = 2
-    o64.loss_and_grads(x.double(), t.double(), m.double())
-    want64 = o64.grads()
     res = {}
     for specialised in (True, False):
         eng = UnetEngine(spec, fc, latent, B, device="cuda:0", specialised=specialised)
@@ -211,8 +201,25 @@ def test_mfma_path_at_medium_size_against_oracle_and_generic_kernels():
         eng.set_hyper(dropout_rate=0.1, seed=4)
         eng.set_step(2)
         eng.set_dataset(0, x, t, m)
-        res[specialised] = (_grad_dict(eng, eng.forward_backward(0, None, 0, B, slot=0)), eng.read_losses(0, 1)[0],
-                            eng.score(x).cpu().numpy())
+        grads = _grad_dict(eng, eng.forward_backward(0, None, 0, B, slot=0))
+        # the oracle follows this run's ReLU decisions where its own pre-activation is within 1e-5 of zero (one BatchNorm
+        # output landing on the other side of zero switches that element's whole upstream gradient: a summation-order
+        # effect worth percents of a layer's weight gradient, oracle/unet_oracle.py ReluAlign), and nowhere else
+        decisions = hip_relu_decisions(eng, spec.save(), fc, latent, B)      # (before score() overwrites the activations)
+        res[specialised] = (grads, eng.read_losses(0, 1)[0], eng.score(x).cpu().numpy())
+        o = uo.UnetOracle(spec.save(), enc.state_dict(), dec.state_dict(), dropout_rate=0.1, seed=4)
+        o.step_count = 2
+        with uo.ReluAlign(decisions) as al32:
+            (mse, pl, _) = o.loss_and_grads(x, t, m)
+        want = o.grads()
+        # the same in fp64: how far the fp32 oracle itself is from the exact gradient on this model (BatchNorm over FIVE
+        # rows behind the first Linear layer makes the Linear section ill-conditioned: 2e-2 of a tensor's maximum is rounding)
+        o64 = uo.UnetOracle(spec.save(), to64(enc.state_dict()), to64(dec.state_dict()), dropout_rate=0.1, seed=4)
+        o64.step_count = 2
+        with uo.ReluAlign(decisions) as al64:
+            o64.loss_and_grads(x.double(), t.double(), m.double())
+        want64 = o64.grads()
+        assert sum(al64.followed.values()) <= 8, f"ReLU decisions followed: {al64.followed}"
         np.testing.assert_allclose(res[specialised][1], [mse, pl], rtol=3e-5)
         for k, w in want.items():
             if _feeds_batchnorm(k):
@@ -226,6 +233,7 @@ def test_mfma_path_at_medium_size_against_oracle_and_generic_kernels():
             tol = max(rel * max(float(np.abs(w64).max()), 1e-6), 3.0 * own)
             err = float(np.abs(got - w64).max())
             assert err <= tol, f"{k} (specialised={specialised}): |hip - fp64| {err:.3e} > {tol:.3e} (the fp32 oracle's own {own:.3e})"
+    # (o: the last trip's fp32 oracle - like each engine it has seen one training forward, so its running statistics moved once)
     np.testing.assert_allclose(res[True][2], res[False][2], rtol=0, atol=2e-5)
     np.testing.assert_allclose(res[True][2], o.eval_forward(x).numpy(), rtol=0, atol=2e-5)
 
