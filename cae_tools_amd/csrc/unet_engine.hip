@@ -235,10 +235,19 @@ void conv_wgrad(unet_engine* e, const Geom& g, const float* S, const float* L, d
     hipLaunchKernelGGL(k_wgrad, dim3(g.Cs * g.Cl * g.kh * g.kw, split), dim3(256), 0, e->stream, g, S, L, acc);
 }
 
-void chan_sums(unet_engine* e, const float* x, long long bs, int B, int C, int HW, double* sums, int sstride, int want_sq) {
-    int chunks = (int)(((long long)B * HW + 256 * 8 - 1) / (256 * 8));
-    if (chunks > 64) chunks = 64;
+// kernels that end in a workgroup-wide sum + atomics: fewer, longer workgroups (the sum's two barriers and the atomics are a
+// fixed 2-3 us; at 128 chunks a workgroup of the 128 x 128 maps had four loop trips of work in front of them)
+dim3 red_grid(int B, int C, int HW) {
+    static const int target = getenv("CAE_UNET_REDWGS") ? atoi(getenv("CAE_UNET_REDWGS")) : 1280;   // env: tuning runs only
+    int chunks = (int)(((long long)B * HW + 256 * 4 - 1) / (256 * 4));
+    const int want = std::max(4, target / std::max(1, C));     // about `target` workgroups over the C channels
+    if (chunks > want) chunks = want;
     if (chunks < 1) chunks = 1;
+    return dim3(chunks, C);
+}
+
+void chan_sums(unet_engine* e, const float* x, long long bs, int B, int C, int HW, double* sums, int sstride, int want_sq) {
+    const int chunks = (int)red_grid(B, C, HW).x;
     hipLaunchKernelGGL(k_chan_sums, dim3(chunks, C), dim3(256), 0, e->stream, x, bs, B, HW, sums, sstride, want_sq);
 }
 
@@ -266,7 +275,7 @@ void bn_backward(unet_engine* e, const Bn& bn, const float* gA, long long gAbs, 
                  const float* z, long long zbs, int B, int HW, Drop d, float* g_io) {
     // pass 1 only sums; pass 2 forms the masked gradient again from gA / gB / z and writes dz (g_io may alias neither input:
     // the callers pass distinct buffers)
-    hipLaunchKernelGGL(k_bn_bwd_reduce, ew_grid(B, bn.C, HW), dim3(256), 0, e->stream, gA, gAbs, gB, gBbs, z, zbs, B, bn.C,
+    hipLaunchKernelGGL(k_bn_bwd_reduce, red_grid(B, bn.C, HW), dim3(256), 0, e->stream, gA, gAbs, gB, gBbs, z, zbs, B, bn.C,
                        HW, e->f(bn.saved), e->P(bn.gamma), e->P(bn.beta), d, (float*)nullptr, e->dsum(bn.bsums));
     hipLaunchKernelGGL(k_bn_bwd_apply2, ew_grid(B, bn.C, HW), dim3(256), 0, e->stream, gA, gAbs, gB, gBbs, z, zbs, B, bn.C, HW,
                        e->f(bn.saved), e->P(bn.gamma), e->P(bn.beta), d, e->dsum(bn.bsums), (double)B * HW, e->gacc(bn.gamma),
@@ -472,7 +481,7 @@ int forward(unet_engine* e, const float* x, int B, bool train) {
         hipLaunchKernelGGL(k_att_fwd, dim3(B), dim3(256), (size_t)(2 * C + 2 * L.R) * sizeof(float), e->stream, e->f(L.pool),
                            C, L.R, e->P(L.w1), e->P(L.w2), e->f(L.att), e->f(L.hid));
         // the concat pass also accumulates the BatchNorm sums of what it writes
-        hipLaunchKernelGGL(k_scale_concat, ew_grid(B, 2 * C, HW), dim3(256), 0, e->stream, e->f(L.u), e->f(L.att), skip, B, C,
+        hipLaunchKernelGGL(k_scale_concat, red_grid(B, 2 * C, HW), dim3(256), 0, e->stream, e->f(L.u), e->f(L.att), skip, B, C,
                            HW, e->f(L.cat), train ? e->dsum(L.bn.sums) : nullptr);
         const Drop d = make_drop(e, SITE_DEC_CONV + j, train);
         bn_act(e, L.bn, e->f(L.cat), (long long)2 * C * HW, B, HW, train, d, nullptr, e->f(L.din_next));
@@ -542,7 +551,7 @@ int backward(unet_engine* e, const float* x, int B) {
                            e->f(Pv.pool), e->f(Pv.att), e->f(Pv.hid), e->f(Pv.da), Cp, Pv.R, e->P(Pv.w1), e->P(Pv.w2),
                            e->gacc(Pv.w1), e->gacc(Pv.w2), e->f(Pv.dpool));
         // ... and accumulates the previous layer's bias gradient while it writes du
-        hipLaunchKernelGGL(k_scale_bwd, ew_grid(B, Cp, HWp), dim3(256), 0, e->stream, e->f(Pv.gcat), e->f(Pv.att),
+        hipLaunchKernelGGL(k_scale_bwd, red_grid(B, Cp, HWp), dim3(256), 0, e->stream, e->f(Pv.gcat), e->f(Pv.att),
                            e->f(Pv.pool), e->f(Pv.dpool), B, Cp, HWp, e->f(Pv.gu), e->gacc(Pv.b));
     }
     // decoder_lin / encoder_lin backward
