@@ -894,21 +894,41 @@ __global__ void __launch_bounds__(256) k_loss_finalize(const double* __restrict_
     }
 }
 
-// du = dL/dp * p * (1 - p),  p = sigmoid(u).  grid-stride over (B*C*HW)
+// du = dL/dp * p * (1 - p),  p = sigmoid(u), and the last layer's bias gradient bias_acc[c] += sum du (nullptr: not wanted).
+// grid (chunks, B*C): a workgroup walks a slice of one (b, c) plane, 16-byte accesses when HW % 4 == 0
 __global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ u, LossSrc ls_src, int B, int C, int HW,
-                                                   const float* __restrict__ coef, float* __restrict__ du) {
-    const long long total = (long long)B * C * HW;
-    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
-        const long long i = o % HW;
-        const long long bc = o / HW;
-        const long long b = bc / C, c = bc - b * C;
-        const long long smp = ls_src.perm ? (long long)ls_src.perm[ls_src.start + b] : ls_src.start + b;
-        const float t = ls_src.target[(smp * C + c) * HW + i];
-        const float m = ls_src.mask ? ls_src.mask[(smp * ls_src.Cm + (ls_src.Cm == 1 ? 0 : c)) * HW + i] : 1.f;
-        const float p = sigmoidf(u[o]);
-        const float4 k = reinterpret_cast<const float4*>(coef)[bc];
+                                                   const float* __restrict__ coef, float* __restrict__ du,
+                                                   double* __restrict__ bias_acc) {
+    __shared__ double red[4];
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+    const long long smp = ls_src.perm ? (long long)ls_src.perm[ls_src.start + b] : ls_src.start + b;
+    const float* tp = ls_src.target + (smp * C + c) * HW;
+    const float* mp = ls_src.mask ? ls_src.mask + (smp * ls_src.Cm + (ls_src.Cm == 1 ? 0 : c)) * HW : nullptr;
+    const float* up = u + (long long)bc * HW;
+    float* dp_out = du + (long long)bc * HW;
+    const float4 k = reinterpret_cast<const float4*>(coef)[bc];
+    double s = 0.0;
+    auto one = [&](float uv, float t, float m) {
+        const float p = sigmoidf(uv);
         const float dp = m * (k.x + k.y * t + k.z * p) + k.w * m * m * (p - t);
-        du[o] = dp * p * (1.f - p);
+        const float d = dp * p * (1.f - p);
+        s += (double)d;
+        return d;
+    };
+    if ((HW & 3) == 0) {
+        for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < HW; i += gridDim.x * 1024) {
+            const float4 uv = *reinterpret_cast<const float4*>(up + i), t = *reinterpret_cast<const float4*>(tp + i);
+            const float4 m = mp ? *reinterpret_cast<const float4*>(mp + i) : make_float4(1.f, 1.f, 1.f, 1.f);
+            float4 d;
+            d.x = one(uv.x, t.x, m.x), d.y = one(uv.y, t.y, m.y), d.z = one(uv.z, t.z, m.z), d.w = one(uv.w, t.w, m.w);
+            *reinterpret_cast<float4*>(dp_out + i) = d;
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) dp_out[i] = one(up[i], tp[i], mp ? mp[i] : 1.f);
+    }
+    if (bias_acc) {
+        const double t = block_sum(s, red);
+        if (threadIdx.x == 0 && t != 0.0) atomicAdd(&bias_acc[c], t);
     }
 }
 

@@ -513,9 +513,19 @@ int loss_forward(unet_engine* e, int which, const int32_t* perm, int64_t start, 
     double* out2 = reinterpret_cast<double*>(e->ws + e->off_losses) + 2 * (size_t)slot;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, e->stream, ls, B, C, src.Cm, src.mask ? 1 : 0, e->lambda_p,
                        out2, want_grad ? e->f(e->coef) : nullptr);
-    if (want_grad)
-        hipLaunchKernelGGL(k_loss_grad, dim3(blocks_for((long long)B * C * HW, 65536)), dim3(256), 0, e->stream, e->f(L.u),
-                           src, B, C, HW, e->f(e->coef), e->f(L.gu));
+    if (want_grad) {
+        // ... and, in the same pass, the last layer's bias gradient (its sum over the batch and the map); backward() clears the
+        // accumulator before anything else adds to it, so the clear is issued here, ahead of this launch
+        if (!e->gacc_clean) {
+            UHIP_TRY(hipMemsetAsync(e->gacc(0), 0, (size_t)e->n_params * sizeof(double), e->stream));
+            for (int k = 0; k < 4; k++) e->fc_f32_dirty[k] = false;
+            e->gacc_clean = true;
+        }
+        int chunks = std::max(1, std::min(64, 1536 / std::max(1, B * C)));
+        chunks = std::min(chunks, (HW + 1023) / 1024);
+        hipLaunchKernelGGL(k_loss_grad, dim3(std::max(1, chunks), B * C), dim3(256), 0, e->stream, e->f(L.u), src, B, C, HW, e->f(e->coef),
+                           e->f(L.gu), e->gacc(L.b));
+    }
     UHIP_TRY(hipGetLastError());
     return CAE_OK;
 }
@@ -536,8 +546,7 @@ int backward(unet_engine* e, const float* x, int B) {
         const float* din = j == 0 ? e->f(e->fc[3].a) : e->f(e->dec[j - 1].din_next);
         // ConvTranspose2d: S = input, L = output
         conv_wgrad(e, g, din, e->f(L.gu), e->gacc(L.w));
-        // bias gradient: summed by k_scale_bwd when it produced gu; the last layer's gu comes from the loss kernel
-        if (j == nd - 1) chan_sums(e, e->f(L.gu), (long long)C * HWl, B, C, HWl, e->gacc(L.b), 1, 0);
+        // bias gradient: summed by k_scale_bwd when it produced gu, and by the loss kernel for the last layer
         conv_down(e, g, e->f(L.gu), e->P(L.w), nullptr, e->f(L.gdin));
         if (j == 0) break;
         // gdin is the gradient wrt dropout(relu(bn(cat_{j-1})))
