@@ -366,5 +366,118 @@ inline void thin_down_launch(const Geom& g, const float* L, const float* w, cons
     else thin_down_launch_cl<2>(g, L, w, bias, S, s);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+//   k_thin_up      L[b][cl][2q+ky-1][2r+kx-1] += S[b][cs][q][r] * w[cs][cl][ky][kx]  (+ bias)      ConvTranspose2d forward,
+//                  CL <= 4 output channels (the 64 -> 3 layer), maps 128 columns wide
+// This one is not a GEMM (three useful rows of 32): it is 96 multiply-adds per input value on the vector pipes.  A wave spans a
+// whole input row - lane l owns columns 2l and 2l + 1, the left / right neighbours come from the adjacent lanes by one-lane DPP
+// shifts (the row's ends are the map's edges: zeros) - and walks a band of T input rows per input channel with the band's
+// 2T x 4 x CL outputs in registers: one 8-byte load per lane, row and channel instead of the nine 4-byte gathers per position
+// of k_up_thin, the next channel's rows in flight.  The four output columns of a lane are two float pairs so that the
+// multiply-adds are packed (v_pk_fma_f32): pair0 += (b, b) * (w1, w2) + (a, c) * (w3, w0), pair1 += (c, c) * (w1, w2) + (b, d) *
+// (w3, w0) for the inputs a b c d = columns 2l-1 .. 2l+2; wq holds the taps in that order (k_pack_thin_up).
+// grid B * Hs / T waves (4 per workgroup), block 256
+typedef float thin_f2 __attribute__((ext_vector_type(2)));
+
+// wq[((cs * CL + cl) * 4 + ky) * 4 + {0,1,2,3}] = w[cs][cl][ky][{1,2,3,0}]
+__global__ void __launch_bounds__(256) k_pack_thin_up(int n, const float* __restrict__ w, float* __restrict__ wq) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) wq[i] = w[(i & ~3) + ((i + 1) & 3)];
+}
+
+__device__ __forceinline__ float thin_from_right(float v) {      // lane i <- lane i + 1 (lane 63: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float thin_from_left(float v) {       // lane i <- lane i - 1 (lane 0: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+
+template <int CL, int T>
+__global__ void __launch_bounds__(256) k_thin_up(Geom g, const float* __restrict__ S, const float* __restrict__ wq,
+                                                 const float* __restrict__ bias, float* __restrict__ L) {
+    const int lane = threadIdx.x & 63;
+    const int bands = g.Hs / T;
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));     // (image, band): wave-uniform
+    if (wid >= g.B * bands) return;
+    const int b = wid / bands, q0 = (wid - b * bands) * T;
+    thin_f2 acc[2 * T][CL][2];
+#pragma unroll
+    for (int o = 0; o < 2 * T; o++)
+#pragma unroll
+        for (int cl = 0; cl < CL; cl++) {
+            const float bv = bias ? bias[cl] : 0.f;
+            acc[o][cl][0] = thin_f2{bv, bv}, acc[o][cl][1] = thin_f2{bv, bv};
+        }
+    const long long plane = (long long)g.Hs * g.Ws;
+    const float* sp = S + (long long)b * g.Cs * plane + 2 * lane;
+    thin_f2 cur[T + 2], nxt[T + 2], nx2[T + 2];       // the rows of channel cs, cs + 1, cs + 2
+    auto load = [&](thin_f2 (&r)[T + 2], int cs) {
+#pragma unroll
+        for (int d = 0; d < T + 2; d++) {
+            const int q = q0 - 1 + d;
+            r[d] = (cs < g.Cs && q >= 0 && q < g.Hs) ? *reinterpret_cast<const thin_f2*>(sp + cs * plane + (long long)q * g.Ws) : thin_f2{0.f, 0.f};
+        }
+    };
+    load(cur, 0);
+    load(nxt, 1);
+    for (int cs = 0; cs < g.Cs; cs++) {
+        load(nx2, cs + 2);
+        const float4* wp = reinterpret_cast<const float4*>(wq) + (size_t)cs * CL * 4;      // wave-uniform: scalar loads
+#pragma unroll
+        for (int d = 0; d < T + 2; d++) {
+            const float bb = cur[d].x, cc = cur[d].y;
+            const float aa = thin_from_left(cc), dd = thin_from_right(bb);
+            const thin_f2 vb{bb, bb}, vc{cc, cc}, vac{aa, cc}, vbd{bb, dd};
+#pragma unroll
+            for (int ky = 0; ky < 4; ky++) {
+                const int o = 2 * (d - 1) + ky - 1;          // output row inside the band: input row q0 - 1 + d, tap ky
+                if (o < 0 || o >= 2 * T) continue;
+#pragma unroll
+                for (int cl = 0; cl < CL; cl++) {
+                    const float4 wv = wp[cl * 4 + ky];
+                    const thin_f2 w12{wv.x, wv.y}, w30{wv.z, wv.w};
+                    acc[o][cl][0] = __builtin_elementwise_fma(vb, w12, acc[o][cl][0]);
+                    acc[o][cl][0] = __builtin_elementwise_fma(vac, w30, acc[o][cl][0]);
+                    acc[o][cl][1] = __builtin_elementwise_fma(vc, w12, acc[o][cl][1]);
+                    acc[o][cl][1] = __builtin_elementwise_fma(vbd, w30, acc[o][cl][1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < T + 2; d++) cur[d] = nxt[d], nxt[d] = nx2[d];
+    }
+#pragma unroll
+    for (int o = 0; o < 2 * T; o++)
+#pragma unroll
+        for (int cl = 0; cl < CL; cl++)
+            *reinterpret_cast<float4*>(L + (((long long)b * CL + cl) * g.Hl + 2 * q0 + o) * g.Wl + 4 * lane) =
+                make_float4(acc[o][cl][0].x, acc[o][cl][0].y, acc[o][cl][1].x, acc[o][cl][1].y);
+}
+
+inline bool thin_up_geom(const Geom& g) {
+    return g.kh == 4 && g.kw == 4 && g.s == 2 && g.p == 1 && g.Hl == 2 * g.Hs && g.Wl == 2 * g.Ws && g.Cl >= 1 && g.Cl <= 4 &&
+           g.Ws == 128 && g.Hs % 2 == 0 && (long long)g.B * g.Cs * g.Hs * g.Ws < (1ll << 31);
+}
+// wq: room for Cs * Cl * 16 floats
+inline void thin_up_launch(const Geom& g, const float* S, const float* w, float* wq, const float* bias, float* L, hipStream_t s) {
+    const int n = g.Cs * g.Cl * 16;
+    hipLaunchKernelGGL(k_pack_thin_up, dim3((n + 255) / 256), dim3(256), 0, s, n, w, wq);
+    static const int t_env = getenv("CAE_THIN_UP_T") ? atoi(getenv("CAE_THIN_UP_T")) : 2;   // env: tuning runs only
+    const int T = (t_env == 4 && g.Hs % 4 == 0) ? 4 : 2;
+    const int waves = g.B * (g.Hs / T);
+    const dim3 grid((waves + 3) / 4);
+#define THIN_UP_CASE(CL_)                                                                                       \
+    if (T == 4) hipLaunchKernelGGL((k_thin_up<CL_, 4>), grid, dim3(256), 0, s, g, S, wq, bias, L);              \
+    else hipLaunchKernelGGL((k_thin_up<CL_, 2>), grid, dim3(256), 0, s, g, S, wq, bias, L)
+    switch (g.Cl) {
+        case 1: THIN_UP_CASE(1); break;
+        case 2: THIN_UP_CASE(2); break;
+        case 3: THIN_UP_CASE(3); break;
+        default: THIN_UP_CASE(4); break;
+    }
+#undef THIN_UP_CASE
+}
+
 }  // namespace
 }  // namespace unet

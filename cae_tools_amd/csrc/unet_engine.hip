@@ -199,6 +199,11 @@ void conv_down(unet_engine* e, const Geom& g, const float* L, const float* w, co
 
 // wp: the layer's repacked weights (pack_up_weights below) or nullptr when the layer does not run the tile engine
 void conv_up(unet_engine* e, const Geom& g, const float* S, const float* w, const float* wp, const float* bias, float* L) {
+    static const int thin_off = getenv("CAE_UNET_THIN") ? atoi(getenv("CAE_UNET_THIN")) == 0 : 0;   // env: A/B measurements only
+    if (e->specialised && !thin_off && wp && thin_up_geom(g)) {   // ... 128 columns wide: the row walk of kernels_unet_thin.h
+        thin_up_launch(g, S, w, const_cast<float*>(wp), bias, L, e->stream);
+        return;
+    }
     if (e->specialised && mfma_geom(g) && g.Cl <= 4) {   // a handful of output channels: streaming kernel, not a GEMM
         const int blocks = blocks_for((long long)g.B * g.Hs * g.Ws, 65536);
         switch (g.Cl) {
@@ -423,7 +428,7 @@ void pack_up_weights(unet_engine* e, bool train) {
     PackSet ps;
     memset(&ps, 0, sizeof ps);
     auto add = [&](const ConvLayer& L) {
-        if (L.wp < 0 || ps.n == 8) return;
+        if (L.wp < 0 || ps.n == 8 || L.g.Cl <= 4) return;      // (Cl <= 4: kernels_unet_thin.h packs its own order)
         ps.Cs[ps.n] = L.g.Cs, ps.Cl[ps.n] = L.g.Cl, ps.w[ps.n] = e->P(L.w), ps.wp[ps.n] = e->f(L.wp);
         ps.begin[ps.n + 1] = ps.begin[ps.n] + (long long)16 * L.g.Cs * L.g.Cl;
         ps.n++;
@@ -813,7 +818,7 @@ int unet_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spe
     auto carve_packed = [&](ConvLayer& L) {
         Geom g = L.g;
         g.B = (int)B;
-        if (mfma_up_eligible(g) && g.Cl > 4) L.wp = F32((int64_t)16 * g.Cs * g.Cl);
+        if ((mfma_up_eligible(g) && g.Cl > 4) || thin_up_geom(g)) L.wp = F32((int64_t)16 * g.Cs * g.Cl);
     };
     for (auto& L : e->dec) carve_packed(L);
     for (size_t i = 1; i < e->enc.size(); i++) carve_packed(e->enc[i]);
