@@ -239,6 +239,7 @@ struct OpWgrad {
     const float* __restrict__ S;
     const float* __restrict__ L;
     double* __restrict__ acc;
+    float* __restrict__ part;   // nullptr: fp64 atomics into acc; else slice z stores its tile at part[(z * Cs + n) * Cl*16 + m]
     int ksplit;   // chunks of 16 per z-slice
     struct Ctx {
         int dummy;
@@ -286,8 +287,13 @@ struct OpWgrad {
         return v;
     }
     __device__ long long col(long long m, int) const { return m < cols() ? m : -1; }
-    __device__ void store(long long cb, int n, float v, int) const {
-        if (n >= g.Cs || cb < 0 || v == 0.f) return;
+    __device__ void store(long long cb, int n, float v, int z) const {
+        if (n >= g.Cs || cb < 0) return;
+        if (part) {
+            part[((size_t)z * g.Cs + n) * (g.Cl * 16) + cb] = v;
+            return;
+        }
+        if (v == 0.f) return;
 #if defined(IG_ABL) && IG_ABL == 4
         if (v != 12345.678f) return;
 #endif
@@ -568,36 +574,73 @@ inline void mfma_up_launch(const Geom& g, const float* S, const float* wp, const
     });
 }
 
-inline void mfma_wgrad_launch(const Geom& g, const float* S, const float* L, double* acc, hipStream_t s) {
+// acc[e] += sum over the K slices of part[z * E + e]: fp64, slices in index order (no atomics: the result does not depend on
+// timing).  grid-stride over E
+__global__ void __launch_bounds__(256) k_wgrad_fold(const float* __restrict__ part, int slices, long long E, double* __restrict__ acc) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long long)gridDim.x * 256) {
+        double s = 0.0;
+        int z = 0;
+        for (; z + 4 <= slices; z += 4) {       // four loads in flight
+            const float p0 = part[(size_t)z * E + e], p1 = part[(size_t)(z + 1) * E + e];
+            const float p2 = part[(size_t)(z + 2) * E + e], p3 = part[(size_t)(z + 3) * E + e];
+            s += (double)p0;
+            s += (double)p1;
+            s += (double)p2;
+            s += (double)p3;
+        }
+        for (; z < slices; z++) s += (double)part[(size_t)z * E + e];
+        acc[e] += s;
+    }
+}
+
+// K slices (blockIdx.z) of the 4-wave tile path for this geometry, and the bytes of partial tiles they would write
+inline int mfma_wgrad_slices(const Geom& g) {
     const int rows = g.Cs;
     const long long cols = (long long)g.Cl * 16;
-#ifndef IG_WG1
-#define IG_WG1 128
-#endif
-    if (cols <= IG_WG1) {   // <= 8 channels on the big side: single-wave 32 x 128 tiles, the parallelism comes from K
-        const int chunks = (g.B * g.Hs * g.Ws + IG_KC - 1) / IG_KC;
-        const int rt = (rows + 31) / 32, ct = (int)((cols + 127) / 128);
-        int per = (int)(((long long)chunks * rt * ct + 2047) / 2048);                // ~2048 single-wave workgroups (8 per CU)
-        if (per < 8) per = 8;
-        OpWgrad<1> op;
-        op.g = g, op.S = S, op.L = L, op.acc = acc, op.ksplit = per;
-        igemm_launch<1, 1>(op, dim3(ct, rt, (chunks + per - 1) / per), s);
-        return;
-    }
     const int TN = rows <= 32 ? 32 : rows <= 64 ? 64 : 128, TM = rows <= 32 ? 512 : rows <= 64 ? 256 : 128;
     const long long tiles = ((rows + TN - 1) / TN) * ((cols + TM - 1) / TM);
     const int chunks = (g.B * g.Hs * g.Ws + IG_KC - 1) / IG_KC;
 #ifndef IG_WGRAD_BLOCKS
 #define IG_WGRAD_BLOCKS 512
 #endif
-    long long want = (IG_WGRAD_BLOCKS + tiles - 1) / tiles;   // workgroups to aim at: every one ends in rows*cols fp64 atomics
+    long long want = (IG_WGRAD_BLOCKS + tiles - 1) / tiles;   // workgroups to aim at
     if (want < 1) want = 1;
     int per = (int)((chunks + want - 1) / want);
     if (per < 8) per = 8;                                 // at least 128 pixels per slice
-    const int zdim = (chunks + per - 1) / per;
+    return (chunks + per - 1) / per;
+}
+inline size_t mfma_wgrad_part_bytes(const Geom& g) {
+#ifndef IG_WG1
+#define IG_WG1 128
+#endif
+    if ((long long)g.Cl * 16 <= IG_WG1) return 0;         // the single-wave path keeps its atomics
+    return (size_t)mfma_wgrad_slices(g) * g.Cs * g.Cl * 16 * sizeof(float);
+}
+
+// part: room for mfma_wgrad_part_bytes(g) (the slices' tiles, folded in order by k_wgrad_fold) or nullptr (fp64 atomics)
+inline void mfma_wgrad_launch(const Geom& g, const float* S, const float* L, double* acc, float* part, hipStream_t s) {
+    const int rows = g.Cs;
+    const long long cols = (long long)g.Cl * 16;
+    if (cols <= IG_WG1) {   // <= 8 channels on the big side: single-wave 32 x 128 tiles, the parallelism comes from K
+        const int chunks = (g.B * g.Hs * g.Ws + IG_KC - 1) / IG_KC;
+        const int rt = (rows + 31) / 32, ct = (int)((cols + 127) / 128);
+        int per = (int)(((long long)chunks * rt * ct + 2047) / 2048);                // ~2048 single-wave workgroups (8 per CU)
+        if (per < 8) per = 8;
+        OpWgrad<1> op;
+        op.g = g, op.S = S, op.L = L, op.acc = acc, op.part = nullptr, op.ksplit = per;
+        igemm_launch<1, 1>(op, dim3(ct, rt, (chunks + per - 1) / per), s);
+        return;
+    }
+    const int chunks = (g.B * g.Hs * g.Ws + IG_KC - 1) / IG_KC;
+    const int zdim = mfma_wgrad_slices(g);
+    const int per = (chunks + zdim - 1) / zdim;
     igemm_dispatch<OpWgrad>(rows, cols, zdim, s, [&](auto& op) {
-        op.g = g, op.S = S, op.L = L, op.acc = acc, op.ksplit = per;
+        op.g = g, op.S = S, op.L = L, op.acc = acc, op.part = part, op.ksplit = per;
     });
+    if (part) {
+        const long long E = (long long)rows * cols;
+        hipLaunchKernelGGL(k_wgrad_fold, dim3((unsigned)std::min<long long>((E + 255) / 256, 4096)), dim3(256), 0, s, part, zdim, E, acc);
+    }
 }
 
 // out[m*o_sm + n*o_sn] = scratch[n*cols + m] + bias[n]; scratch is cleared for the next use

@@ -110,7 +110,7 @@ struct unet_engine {
     // workspace
     int64_t ws_bytes = 0;
     int64_t off_gacc = 0, off_dsum = 0, n_dsum = 0, off_losses = 0, off_ls = 0, off_f32 = 0, off_gscratch = 0, gscratch_bytes = 0;
-    int64_t off_thinpart = 0, thinpart_bytes = 0;   // per-workgroup weight-gradient tiles of the image-end layers (kernels_unet_thin.h)
+    int64_t off_thinpart = 0, thinpart_bytes = 0;   // weight-gradient partial tiles: per workgroup (kernels_unet_thin.h), per K slice (tile engine)
     int64_t off_linpart = 0, linpart_bytes = 0;   // K-slice partial tiles of the big Linear layers (kernels_unet_lin.h)
     bool fc_f32[4] = {false, false, false, false};   // this backward stored fc[k]'s weight gradient as fp32 (F32Ranges)
     bool fc_f32_dirty[4] = {false, false, false, false};   // ... and nothing has cleared those accumulator slots since
@@ -230,7 +230,10 @@ void conv_wgrad(unet_engine* e, const Geom& g, const float* S, const float* L, d
         return;
     }
     if (e->specialised && mfma_wgrad_eligible(g)) {
-        mfma_wgrad_launch(g, S, L, acc, e->stream);
+        static const int part_off = getenv("CAE_UNET_WGPART") ? atoi(getenv("CAE_UNET_WGPART")) == 0 : 0;   // env: A/B measurements only
+        const size_t need = mfma_wgrad_part_bytes(g);
+        float* part = (!part_off && need && need <= (size_t)e->thinpart_bytes) ? reinterpret_cast<float*>(e->ws + e->off_thinpart) : nullptr;
+        mfma_wgrad_launch(g, S, L, acc, part, e->stream);
         return;
     }
     const long long per = (long long)g.B * g.Hs * g.Ws;
@@ -849,6 +852,7 @@ int unet_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spe
         Geom g = L.g;
         g.B = (int)B;
         if (thin_geom(g)) tp = std::max<int64_t>(tp, (int64_t)thin_wgrad_part_bytes(g));
+        else if (mfma_wgrad_eligible(g)) tp = std::max<int64_t>(tp, (int64_t)mfma_wgrad_part_bytes(g));
     };
     for (auto& L : e->enc) thin_need(L);
     for (auto& L : e->dec) thin_need(L);
