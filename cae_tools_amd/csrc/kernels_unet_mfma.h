@@ -65,6 +65,7 @@ struct OpDown {
     struct KCtx {
         long long plane;
     };
+    __device__ void remap(int&, int&, int&) const {}
     __device__ int rows() const { return g.Cs; }
     __device__ long long cols() const { return (long long)g.B * g.Hs * g.Ws; }
     __device__ int k_begin(int z) const { return z * ksplit * IG_KC; }
@@ -170,6 +171,7 @@ struct OpUp {
     struct KCtx {
         int dummy;
     };
+    __device__ void remap(int&, int&, int&) const {}
     __device__ int rows() const { return g.Cl; }
     __device__ long long cols() const { return (long long)g.B * g.Hs * g.Ws; }
     __device__ int k_begin(int) const { return 0; }
@@ -248,6 +250,17 @@ struct OpWgrad {
         bool ok;
         int b, p, y, x0;
     };
+    // workgroups are dealt to the 8 XCDs by linear id mod 8: the tiles of ONE K slice (they read the same slice of both maps)
+    // go to one XCD, so that the slice is fetched into one L2 instead of eight
+    __device__ void remap(int& bx, int& by, int& bz) const {
+        const int gx = gridDim.x, gy = gridDim.y, T = gx * gy;
+        if (gridDim.z & 7) return;
+        const int i = bx + gx * (by + gy * bz), xcd = i & 7, j = i >> 3;
+        const int t = j % T;
+        bz = (j / T) * 8 + xcd;
+        bx = t % gx;
+        by = t / gx;
+    }
     __device__ int rows() const { return g.Cs; }
     __device__ long long cols() const { return (long long)g.Cl * 16; }
     __device__ int ktotal() const { return g.B * g.Hs * g.Ws; }
@@ -330,6 +343,7 @@ struct OpGemm {
     struct KCtx {
         int dummy;
     };
+    __device__ void remap(int&, int&, int&) const {}
     __device__ int rows() const { return nrows; }
     __device__ long long cols() const { return ncols; }
     __device__ int k_begin(int z) const { return z * ksplit * IG_KC; }
@@ -398,9 +412,11 @@ __global__ void __launch_bounds__(256) k_igemm(Op op) {
     float* lds = reinterpret_cast<float*>(lds4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WM, wm = wave - wn * WM;
-    const long long m0 = (long long)blockIdx.x * TM;
-    const int n0 = blockIdx.y * TN;
-    const int z = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    op.remap(bx, by, bz);
+    const long long m0 = (long long)bx * TM;
+    const int n0 = by * TN;
+    const int z = bz;
     typename Op::Ctx ctx;
     op.init(ctx, tid, m0, z);
     f32x16 acc[4];
