@@ -22,7 +22,7 @@ ARCH = "gfx950"
 SOURCES = {
     "engine.hip": ["kernels_generic.h", "kernels_s2.h", "kernels_last.h", "kernels_rows.h", "kernels_gemm.h", "kernels_igemm.h", "kernels_ctlds.h", "kernels_ctbwd.h", "kernels_head.h", "dp_comm.h", "cae_hip.h", "trunk_api.h"],
     "ctbwd.hip": ["kernels_generic.h", "kernels_gemm.h", "kernels_ctbwd.h"],
-    "unet_engine.hip": ["kernels_unet.h", "kernels_unet_mfma.h", "kernels_unet_lin.h", "kernels_unet_thin.h", "kernels_generic.h", "kernels_gemm.h", "cae_unet.h", "cae_hip.h"],
+    "unet_engine.hip": ["kernels_unet.h", "kernels_unet_mfma.h", "kernels_unet_lin.h", "kernels_unet_thin.h", "kernels_unet_patch.h", "kernels_generic.h", "kernels_gemm.h", "cae_unet.h", "cae_hip.h"],
     "vae_engine.hip": ["kernels_unet.h", "kernels_vae.h", "cae_vae.h", "cae_hip.h", "trunk_api.h"],
     "linear_engine.hip": ["kernels_unet.h", "kernels_unet_mfma.h", "kernels_vae.h", "cae_linear.h", "cae_hip.h"],
 }

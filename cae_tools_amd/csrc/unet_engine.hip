@@ -17,6 +17,7 @@
 #include "kernels_unet_mfma.h"
 #include "kernels_unet_lin.h"
 #include "kernels_unet_thin.h"
+#include "kernels_unet_patch.h"
 
 // The ConvAE path's 16x16-tile MFMA GEMM (kernels_gemm.h: four waves split K, one launch for a Linear layer's weight gradient
 // beside its input gradient) for the SMALL Linear layers here (fc -> latent -> fc): the convolution tile engine's strided
@@ -187,6 +188,11 @@ void conv_down(unet_engine* e, const Geom& g, const float* L, const float* w, co
     static const int thin_off = getenv("CAE_UNET_THIN") ? atoi(getenv("CAE_UNET_THIN")) == 0 : 0;   // env: A/B measurements only
     if (e->specialised && !thin_off && thin_geom(g)) {   // the image-end layers: kernels_unet_thin.h
         thin_down_launch(g, L, w, bias, S, e->stream);
+        return;
+    }
+    static const int patch_off = getenv("CAE_UNET_PATCH") ? atoi(getenv("CAE_UNET_PATCH")) == 0 : 0;   // env: A/B measurements only
+    if (e->specialised && !patch_off && patch_geom(g)) {   // the wide layers: kernels_unet_patch.h
+        pdown_launch(g, L, w, bias, S, e->stream);
         return;
     }
     if (e->specialised && mfma_down_eligible(g)) {
