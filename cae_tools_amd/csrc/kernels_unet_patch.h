@@ -174,5 +174,155 @@ inline void pdown_launch(const Geom& g, const float* L, const float* w, const fl
     else hipLaunchKernelGGL(k_pdown<4>, grid, dim3(256), lds, s, g, L, w, bias, S, gper, nsplit);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+//   k_pup     L[b][cl][2q+py][2r+px] = bias[cl] + sum_{cs,j,i} S[b][cs][q+py-j][r+px-i] * w[cs][cl][1-py+2j][1-px+2i]
+//             (ConvTranspose2d forward of the decoder; input gradient of the encoder's Conv2d layers)
+// per output-row parity py (blockIdx.z) and for BOTH column parities at once: D_px[cl][p] = sum_k Wz[cl][k] * patch(k, p), k = (cs,
+// j, i), with the weights repacked per parity as the tile engine has them (k_pack_up_weights: wp[z][cl][cs*4 + j*2 + i]).  The
+// patch is the R + 2 rows of S around the tile's 128 input pixels, unit stride: an MFMA step's two k values are the taps j = 0
+// and j = 1 of one (channel, i), one patch row apart (row pitch = 32 mod 64: lanes 0-31 on 32 consecutive banks, lanes 32-63 on
+// the other 32); the three column shifts r-1, r, r+1 serve both column parities, and a lane's two results (px = 0, 1) are
+// adjacent in memory: 8-byte stores, a wave's run is 512 contiguous bytes.
+constexpr int kPupCG = 8;              // input channels per K chunk (K = 32)
+constexpr int kPupWP = 4 * kPupCG + 4; // pitch of a weight chunk [row][32]
+
+inline bool pup_geom(const Geom& g) {
+    return g.kh == 4 && g.kw == 4 && g.s == 2 && g.p == 1 && g.Hl == 2 * g.Hs && g.Wl == 2 * g.Ws &&
+           (g.Ws == 16 || g.Ws == 32 || g.Ws == 64 || g.Ws == 128) && g.Hs % (kPatchPx / g.Ws) == 0 && g.Cs % kPupCG == 0 && g.Cs >= 16 &&
+           g.Cl >= 32 && (long long)g.B * g.Cs * g.Hs * g.Ws < (1ll << 31) && (long long)g.B * g.Cl * g.Hl * g.Wl < (1ll << 31);
+}
+__host__ __device__ inline PatchShape pup_shape(const Geom& g) {
+    PatchShape s;
+    s.R = kPatchPx / g.Ws;
+    s.rowp = g.Ws == 16 ? 48 : g.Ws == 128 ? 160 : 96;      // >= Ws + 5, = 32 mod 64 (48 for the two-row blocks of a 16-wide map)
+    s.planep = (s.R + 2) * s.rowp;
+    s.tiles = g.Hs / s.R;
+    return s;
+}
+inline size_t pup_lds_bytes(const Geom& g, int rbn) {
+    return (size_t)(2 * 32 * rbn * kPupWP + kPupCG * pup_shape(g).planep) * sizeof(float);
+}
+
+// grid (B * tiles, ceil(Cl / (32 RBN)), 2 = py), block 256, dynamic LDS pup_lds_bytes
+template <int RBN>
+__global__ void __launch_bounds__(256) k_pup(Geom g, const float* __restrict__ S, const float* __restrict__ wp,
+                                             const float* __restrict__ bias, float* __restrict__ L) {
+    constexpr int TN = 32 * RBN;
+    extern __shared__ float4 patch_lds4[];
+    float* Wt = reinterpret_cast<float*>(patch_lds4);        // [2 = px][TN][36]
+    float* Sp = Wt + 2 * TN * kPupWP;                        // [8][planep]
+    const PatchShape sh = pup_shape(g);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int b = blockIdx.x / sh.tiles, q0 = (blockIdx.x - b * sh.tiles) * sh.R;
+    const int n0 = blockIdx.y * TN, py = blockIdx.z;
+    const int W4 = g.Ws >> 2, prow = sh.R + 2;
+    const int lunits = kPupCG * prow * W4;                   // <= 768 float4s
+
+    for (int i = tid; i < kPupCG * sh.planep; i += 256) Sp[i] = 0.f;           // pads and borders stay zero
+
+    int l_lds[3];
+    long long l_map[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int u = tid + 256 * i;
+        const int c4 = u % W4, rr = u / W4, lr = rr % prow, c = rr / prow;
+        const int q = q0 - 1 + lr;
+        const bool ok = u < lunits && q >= 0 && q < g.Hs;
+        l_lds[i] = u < lunits ? c * sh.planep + lr * sh.rowp + 4 + 4 * c4 : -1;
+        l_map[i] = ok ? (((long long)b * g.Cs + c) * g.Hs + q) * g.Ws + 4 * c4 : -1;
+    }
+    const long long cplane = (long long)g.Hs * g.Ws;
+    const int kw = g.Cs * 4;                                  // k length of a packed weight row
+    // weights: 2 (px) x TN rows x 8 float4s per chunk
+    const int wc4 = tid & 7, wr0 = tid >> 3;                 // column quad wc4 of rows wr0, wr0 + 32, ... of px 0, then of px 1
+    float4 wreg[2 * RBN], lreg[3];
+    auto fetch = [&](int cg) {
+#pragma unroll
+        for (int i = 0; i < 2 * RBN; i++) {
+            const int px = i / RBN, n = n0 + wr0 + 32 * (i % RBN);
+            wreg[i] = n < g.Cl ? *reinterpret_cast<const float4*>(wp + ((size_t)(2 * py + px) * g.Cl + n) * kw + cg * (4 * kPupCG) + 4 * wc4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            lreg[i] = l_map[i] >= 0 ? *reinterpret_cast<const float4*>(S + l_map[i] + (long long)cg * kPupCG * cplane)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2 * RBN; i++)
+            *reinterpret_cast<float4*>(Wt + ((i / RBN) * TN + wr0 + 32 * (i % RBN)) * kPupWP + 4 * wc4) = wreg[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (l_lds[i] >= 0) *reinterpret_cast<float4*>(Sp + l_lds[i]) = lreg[i];
+    };
+
+    patch_f32x16 acc[2][RBN];
+#pragma unroll
+    for (int px = 0; px < 2; px++)
+#pragma unroll
+        for (int rb = 0; rb < RBN; rb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[px][rb][r] = 0.f;
+
+    // this lane's input pixel inside the tile; its taps: patch row ql + py + 1 - j (j = h), columns r - 1, r, r + 1
+    const int p = 32 * wave + (lane & 31), ql = p / g.Ws, r = p - ql * g.Ws;
+    const float* bcol = Sp + (ql + py + 1 - h) * sh.rowp + 4 + r;
+    const float* arow = Wt + (lane & 31) * kPupWP + 2 * h;
+
+    const int chunks = g.Cs / kPupCG;
+    fetch(0);
+    for (int cg = 0; cg < chunks; cg++) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (cg + 1 < chunks) fetch(cg + 1);
+#pragma unroll
+        for (int c = 0; c < kPupCG; c++) {
+            float2 a2[2][RBN];
+#pragma unroll
+            for (int px = 0; px < 2; px++)
+#pragma unroll
+                for (int rb = 0; rb < RBN; rb++)
+                    a2[px][rb] = *reinterpret_cast<const float2*>(arow + (px * TN + 32 * rb) * kPupWP + c * 4);
+            const float bm = bcol[c * sh.planep - 1], b0 = bcol[c * sh.planep], bp = bcol[c * sh.planep + 1];
+#pragma unroll
+            for (int rb = 0; rb < RBN; rb++) {
+                acc[0][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][rb].x, b0, acc[0][rb], 0, 0, 0);      // px 0, i 0: column r
+                acc[1][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][rb].x, bp, acc[1][rb], 0, 0, 0);      // px 1, i 0: column r + 1
+            }
+#pragma unroll
+            for (int rb = 0; rb < RBN; rb++) {
+                acc[0][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][rb].y, bm, acc[0][rb], 0, 0, 0);      // px 0, i 1: column r - 1
+                acc[1][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][rb].y, b0, acc[1][rb], 0, 0, 0);      // px 1, i 1: column r
+            }
+        }
+    }
+    const long long plane = (long long)g.Hl * g.Wl;
+    float* out = L + ((long long)b * g.Cl + n0 + 4 * h) * plane + (long long)(2 * (q0 + ql) + py) * g.Wl + 2 * r;
+#pragma unroll
+    for (int rb = 0; rb < RBN; rb++)
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) {
+            const int row = 32 * rb + (rr >> 2) * 8 + (rr & 3);       // + 4 h: in `out`
+            const int n = n0 + row + 4 * h;
+            if (n >= g.Cl) continue;
+            const float bv = bias ? bias[n] : 0.f;
+            *reinterpret_cast<float2*>(out + (long long)row * plane) = make_float2(acc[0][rb][rr] + bv, acc[1][rb][rr] + bv);
+        }
+}
+
+// wp: the layer's weights repacked per parity by k_pack_up_weights
+inline void pup_launch(const Geom& g, const float* S, const float* wp, const float* bias, float* L, hipStream_t s) {
+    const PatchShape sh = pup_shape(g);
+    const int rbn = g.Cl <= 32 ? 1 : 2;
+    const int TN = 32 * rbn;
+    const dim3 grid((unsigned)(g.B * sh.tiles), (g.Cl + TN - 1) / TN, 2);
+    const size_t lds = pup_lds_bytes(g, rbn);
+    if (rbn == 1) hipLaunchKernelGGL(k_pup<1>, grid, dim3(256), lds, s, g, S, wp, bias, L);
+    else hipLaunchKernelGGL(k_pup<2>, grid, dim3(256), lds, s, g, S, wp, bias, L);
+}
+
 }  // namespace
 }  // namespace unet

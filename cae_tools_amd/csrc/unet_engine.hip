@@ -220,6 +220,11 @@ void conv_up(unet_engine* e, const Geom& g, const float* S, const float* w, cons
         }
         return;
     }
+    static const int patch_off = getenv("CAE_UNET_PATCH") ? atoi(getenv("CAE_UNET_PATCH")) == 0 : 0;   // env: A/B measurements only
+    if (e->specialised && !patch_off && wp && g.Cl > 4 && pup_geom(g)) {   // the wide layers: kernels_unet_patch.h
+        pup_launch(g, S, wp, bias, L, e->stream);
+        return;
+    }
     if (e->specialised && wp && mfma_up_eligible(g)) {
         mfma_up_launch(g, S, wp, bias, L, e->stream);
         return;
