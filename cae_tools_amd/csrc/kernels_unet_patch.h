@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "kernels_unet.h"
+#include "kernels_unet_mfma.h"
 
 namespace unet {
 namespace {
@@ -322,6 +323,176 @@ inline void pup_launch(const Geom& g, const float* S, const float* wp, const flo
     const size_t lds = pup_lds_bytes(g, rbn);
     if (rbn == 1) hipLaunchKernelGGL(k_pup<1>, grid, dim3(256), lds, s, g, S, wp, bias, L);
     else hipLaunchKernelGGL(k_pup<2>, grid, dim3(256), lds, s, g, S, wp, bias, L);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+//   k_pwgrad  dW[cs][cl][ky][kx] = sum_{b,y,x} S[b][cs][y][x] * L[b][cl][2y-1+ky][2x-1+kx]      (weight gradient of either layer kind)
+// as D[cs][t] = sum_p S[cs][p] * patch(t, p), t = (cl, ky, kx): rows = 32 WR channels of S, columns = 128 taps = eight channels of L,
+// K = pixels in tiles of 64 (64 / Ws map rows).  The S tile is a [rows][64 + 4] LDS image (one ds_read_b128 = four k steps of a
+// row); the patch holds the eight channels' 2R + 2 rows, zero-bordered as in k_pdown, and is read in place: an MFMA step
+// multiplies the pixel pair {p, p + 16}; lanes 0-31 are 32 taps of pixel p - kx, then ky (row pitch = 4 mod 64), then the
+// channel (plane pitch = 16 mod 64): 32 consecutive banks - lanes 32-63 the same taps 16 pixels on (32 floats: the other 32
+// banks; 16-wide maps put that pixel two patch rows down and pay a two-way conflict).  A workgroup walks `tpw` pixel tiles with
+// the next tile's loads in flight and leaves its 32 WR x 128 tile at part[(slice * Cs + n) * 16 Cl + t] for k_wgrad_fold.
+// WR x WC = 4 waves: a wave owns 32 rows x 128 / WC columns.   grid (Cl / 8, ceil(Cs / (32 WR)), slices), block 256
+constexpr int kPwPx = 64;            // pixels per K tile
+constexpr int kPwSP = kPwPx + 4;     // pitch of the S tile
+
+inline bool pwgrad_geom(const Geom& g) {
+    return g.kh == 4 && g.kw == 4 && g.s == 2 && g.p == 1 && g.Hl == 2 * g.Hs && g.Wl == 2 * g.Ws &&
+           (g.Ws == 16 || g.Ws == 32 || g.Ws == 64) && g.Hs % (kPwPx / g.Ws) == 0 && g.Cl % 8 == 0 && g.Cs >= 64 &&
+           (long long)g.B * g.Cs * g.Hs * g.Ws < (1ll << 31) && (long long)g.B * g.Cl * g.Hl * g.Wl < (1ll << 31);
+}
+__host__ __device__ inline PatchShape pwgrad_shape(const Geom& g) {
+    PatchShape s;
+    s.R = kPwPx / g.Ws;
+    s.rowp = g.Wl + 4;
+    const int raw = (2 * s.R + 2) * s.rowp;
+    s.planep = raw + ((16 - raw % 64) + 64) % 64;
+    s.tiles = g.Hs / s.R;            // per image
+    return s;
+}
+inline size_t pwgrad_lds_bytes(const Geom& g, int wr) {
+    return (size_t)(32 * wr * kPwSP + 8 * pwgrad_shape(g).planep + 4) * sizeof(float);
+}
+
+template <int WR, int WC>
+__global__ void __launch_bounds__(256) k_pwgrad(Geom g, const float* __restrict__ S, const float* __restrict__ L,
+                                                float* __restrict__ part, int tpw) {
+    constexpr int TN = 32 * WR, NCB = 4 / WC;                // rows per workgroup, column blocks per wave
+    extern __shared__ float4 patch_lds4[];
+    float* Ss = reinterpret_cast<float*>(patch_lds4);        // [TN][68]
+    float* Lp = Ss + TN * kPwSP;                             // [8][planep] + 4
+    const PatchShape sh = pwgrad_shape(g);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int wr = wave / WC, wc = wave - wr * WC;
+    const int cl0 = blockIdx.x * 8, n0 = blockIdx.y * TN;
+    const int total = g.B * sh.tiles;                        // pixel tiles in the batch
+    const int t_begin = blockIdx.z * tpw, t_end = min(total, t_begin + tpw);
+    const int W4 = g.Wl >> 2, prow = 2 * sh.R + 2;
+    const int lunits = 8 * prow * W4;                        // <= 1024 float4s
+
+    for (int i = tid; i < 8 * sh.planep + 4; i += 256) Lp[i] = 0.f;            // pads and borders stay zero
+
+    int l_lds[4], l_row[4], l_off[4];                        // patch float4s of this thread: LDS offset, patch row, offset in the map
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int u = tid + 256 * i;
+        const int c4 = u % W4, rr = u / W4, lr = rr % prow, c = rr / prow;
+        l_row[i] = u < lunits ? lr : -1;
+        l_lds[i] = c * sh.planep + lr * sh.rowp + 4 + 4 * c4;
+        l_off[i] = (cl0 + c) * g.Hl * g.Wl + 4 * c4;         // + (b * Cl * Hl + Y) * Wl
+    }
+    const int sc4 = tid & 15, sr0 = tid >> 4;                // S tile: column quad sc4 of rows sr0, sr0 + 16, ...
+    float4 sreg[2 * WR], lreg[4];
+    auto fetch = [&](int ti) {
+        const int b = ti / sh.tiles, y0 = (ti - b * sh.tiles) * sh.R;
+#pragma unroll
+        for (int i = 0; i < 2 * WR; i++) {
+            const int n = n0 + sr0 + 16 * i;
+            sreg[i] = n < g.Cs ? *reinterpret_cast<const float4*>(S + (((long long)b * g.Cs + n) * g.Hs + y0) * g.Ws + 4 * sc4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const long long lb = (long long)b * g.Cl * g.Hl * g.Wl;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int Y = 2 * y0 - 1 + l_row[i];
+            lreg[i] = (l_row[i] >= 0 && Y >= 0 && Y < g.Hl) ? *reinterpret_cast<const float4*>(L + lb + l_off[i] + (long long)Y * g.Wl)
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2 * WR; i++) *reinterpret_cast<float4*>(Ss + (sr0 + 16 * i) * kPwSP + 4 * sc4) = sreg[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (l_row[i] >= 0) *reinterpret_cast<float4*>(Lp + l_lds[i]) = lreg[i];
+    };
+
+    patch_f32x16 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
+
+    // A: this wave's 32 rows, pixel 16 h + ...; B: this lane's tap of column block cb, pixel offsets added per step
+    const float* arow = Ss + (32 * wr + (lane & 31)) * kPwSP + 16 * h;
+    const int yh = (16 * h) / g.Ws, xh = (16 * h) - yh * g.Ws;
+    const float* bcol[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        const int t = lane & 31, c = 2 * (wc * NCB + cb) + (t >> 4), ky = (t >> 2) & 3, kx = t & 3;
+        bcol[cb] = Lp + c * sh.planep + (ky + 2 * yh) * sh.rowp + kx + 3 + 2 * xh;
+    }
+    int boff[2];                                             // the two 32-pixel blocks of a tile: first pixel's (row, column) in the patch
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {
+        const int yb = (32 * blk) / g.Ws, xb = 32 * blk - yb * g.Ws;
+        boff[blk] = 2 * yb * sh.rowp + 2 * xb;
+    }
+
+    if (t_begin < t_end) fetch(t_begin);
+    for (int ti = t_begin; ti < t_end; ti++) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (ti + 1 < t_end) fetch(ti + 1);
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 a4 = *reinterpret_cast<const float4*>(arow + 32 * blk + 4 * q);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bcol[cb][boff[blk] + 2 * (4 * q + j)], acc[cb], 0, 0, 0);
+            }
+    }
+    const int ncol = g.Cl * 16;
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        const int col = cl0 * 16 + 32 * (wc * NCB + cb) + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int n = n0 + 32 * wr + (r >> 2) * 8 + 4 * h + (r & 3);
+            if (n < g.Cs) part[((size_t)blockIdx.z * g.Cs + n) * ncol + col] = acc[cb][r];
+        }
+    }
+}
+
+// K slices and bytes of partial tiles of a launch
+inline int pwgrad_tpw(const Geom& g) {
+    const int rows = g.Cs >= 128 ? 128 : 64;
+    const long long tiles_out = (long long)(g.Cl / 8) * ((g.Cs + rows - 1) / rows);
+    const int total = g.B * pwgrad_shape(g).tiles;
+    static const int target = getenv("CAE_PWGRAD_WGS") ? atoi(getenv("CAE_PWGRAD_WGS")) : 512;   // env: tuning runs only
+    long long want = (target + tiles_out - 1) / tiles_out;    // slices to aim at: two resident workgroups per CU
+    if (want < 1) want = 1;
+    int tpw = (int)((total + want - 1) / want);
+    if (tpw < 2) tpw = 2;
+    return tpw;
+}
+inline int pwgrad_slices(const Geom& g) {
+    const int total = g.B * pwgrad_shape(g).tiles, tpw = pwgrad_tpw(g);
+    return (total + tpw - 1) / tpw;
+}
+inline size_t pwgrad_part_bytes(const Geom& g) { return (size_t)pwgrad_slices(g) * g.Cs * g.Cl * 16 * sizeof(float); }
+
+// part: room for pwgrad_part_bytes(g)
+inline void pwgrad_launch(const Geom& g, const float* S, const float* L, double* acc, float* part, hipStream_t s) {
+    const int tpw = pwgrad_tpw(g), slices = pwgrad_slices(g);
+    if (g.Cs >= 128) {
+        const dim3 grid(g.Cl / 8, (g.Cs + 127) / 128, slices);
+        hipLaunchKernelGGL((k_pwgrad<4, 1>), grid, dim3(256), pwgrad_lds_bytes(g, 4), s, g, S, L, part, tpw);
+    } else {
+        const dim3 grid(g.Cl / 8, (g.Cs + 63) / 64, slices);
+        hipLaunchKernelGGL((k_pwgrad<2, 2>), grid, dim3(256), pwgrad_lds_bytes(g, 2), s, g, S, L, part, tpw);
+    }
+    const long long E = (long long)g.Cs * g.Cl * 16;
+    hipLaunchKernelGGL(k_wgrad_fold, dim3((unsigned)std::min<long long>((E + 255) / 256, 4096)), dim3(256), 0, s, part, slices, E, acc);
 }
 
 }  // namespace

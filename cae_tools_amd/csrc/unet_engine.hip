@@ -240,6 +240,11 @@ void conv_wgrad(unet_engine* e, const Geom& g, const float* S, const float* L, d
         thin_wgrad_launch(g, S, L, acc, part, e->stream);
         return;
     }
+    static const int patch_off = getenv("CAE_UNET_PATCH") ? atoi(getenv("CAE_UNET_PATCH")) == 0 : 0;   // env: A/B measurements only
+    if (e->specialised && !patch_off && pwgrad_geom(g) && pwgrad_part_bytes(g) <= (size_t)e->thinpart_bytes) {   // kernels_unet_patch.h
+        pwgrad_launch(g, S, L, acc, reinterpret_cast<float*>(e->ws + e->off_thinpart), e->stream);
+        return;
+    }
     if (e->specialised && mfma_wgrad_eligible(g)) {
         static const int part_off = getenv("CAE_UNET_WGPART") ? atoi(getenv("CAE_UNET_WGPART")) == 0 : 0;   // env: A/B measurements only
         const size_t need = mfma_wgrad_part_bytes(g);
@@ -864,6 +869,7 @@ int unet_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spe
         g.B = (int)B;
         if (thin_geom(g)) tp = std::max<int64_t>(tp, (int64_t)thin_wgrad_part_bytes(g));
         else if (mfma_wgrad_eligible(g)) tp = std::max<int64_t>(tp, (int64_t)mfma_wgrad_part_bytes(g));
+        if (pwgrad_geom(g)) tp = std::max<int64_t>(tp, (int64_t)pwgrad_part_bytes(g));
     };
     for (auto& L : e->enc) thin_need(L);
     for (auto& L : e->dec) thin_need(L);
