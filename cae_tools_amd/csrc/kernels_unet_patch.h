@@ -367,9 +367,18 @@ __global__ void __launch_bounds__(256) k_pwgrad(Geom g, const float* __restrict_
     const PatchShape sh = pwgrad_shape(g);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int wr = wave / WC, wc = wave - wr * WC;
-    const int cl0 = blockIdx.x * 8, n0 = blockIdx.y * TN;
+    // workgroups are dealt to the 8 XCDs by linear id mod 8: the output tiles of ONE K slice (they read the same pixel tiles of
+    // both maps) go to one XCD, so that its L2 fetches them once
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if ((gridDim.z & 7) == 0) {
+        const int T = gridDim.x * gridDim.y, i = bx + gridDim.x * (by + gridDim.y * bz), j = i >> 3, t = j % T;
+        bz = (j / T) * 8 + (i & 7);
+        bx = t % gridDim.x;
+        by = t / gridDim.x;
+    }
+    const int cl0 = bx * 8, n0 = by * TN;
     const int total = g.B * sh.tiles;                        // pixel tiles in the batch
-    const int t_begin = blockIdx.z * tpw, t_end = min(total, t_begin + tpw);
+    const int t_begin = bz * tpw, t_end = min(total, t_begin + tpw);
     const int W4 = g.Wl >> 2, prow = 2 * sh.R + 2;
     const int lunits = 8 * prow * W4;                        // <= 1024 float4s
 
@@ -458,7 +467,7 @@ __global__ void __launch_bounds__(256) k_pwgrad(Geom g, const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int n = n0 + 32 * wr + (r >> 2) * 8 + 4 * h + (r & 3);
-            if (n < g.Cs) part[((size_t)blockIdx.z * g.Cs + n) * ncol + col] = acc[cb][r];
+            if (n < g.Cs) part[((size_t)bz * g.Cs + n) * ncol + col] = acc[cb][r];
         }
     }
 }
