@@ -297,6 +297,26 @@ __device__ __forceinline__ bool vec4_ok(int HW, long long s0 = 0, long long s1 =
     return ((HW | s0 | s1 | s2) & 3) == 0;
 }
 
+// The decoder's concatenated tensor (unet.py:157-160: channels 0..Ch-1 = the gated ConvTranspose2d output u * att[b][c], channels
+// Ch..2Ch-1 = the encoder skip) is never materialised: the BatchNorm kernels that would read it take the two sources instead.
+// u == nullptr: an ordinary tensor, z[b * zbs + c * HW + i].
+struct ZCat {
+    const float* u;
+    const float* att;
+    const float* skip;
+    int Ch;
+};
+// plane (b, c) of a BatchNorm input and the factor its values are to be multiplied by (1 for everything but the gated half)
+__device__ __forceinline__ const float* z_plane(const float* z, long long zbs, const ZCat& zc, int b, int c, int HW, float& k) {
+    k = 1.f;
+    if (!zc.u) return z + b * zbs + (long long)c * HW;
+    if (c < zc.Ch) {
+        k = zc.att[(long long)b * zc.Ch + c];
+        return zc.u + ((long long)b * zc.Ch + c) * HW;
+    }
+    return zc.skip + ((long long)b * zc.Ch + (c - zc.Ch)) * HW;
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-channel reductions and BatchNorm (2-d: (B,C,HW); 1-d: HW = 1)
 // ---------------------------------------------------------------------------------------------
@@ -341,7 +361,7 @@ __global__ void __launch_bounds__(256) k_bn_act(const float* __restrict__ z, lon
                                                 float eps, int stat_mode, const double* __restrict__ sums, double N,
                                                 float momentum, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, Drop d, float* __restrict__ s_out,
-                                                float* __restrict__ a_out) {
+                                                float* __restrict__ a_out, ZCat zc) {
     const int c = blockIdx.y;
     float mean, invstd;
     if (stat_mode == 2) {
@@ -368,19 +388,20 @@ __global__ void __launch_bounds__(256) k_bn_act(const float* __restrict__ z, lon
     auto body = [&](auto VT) {
         constexpr int V = decltype(VT)::value;
         plane_loop<V>(B, HW, [&](int b, int i) {
-            VecF<V> t = VecF<V>::ld(z + b * zbs + (long long)c * HW + i);
+            float zk;
+            VecF<V> t = VecF<V>::ld(z_plane(z, zbs, zc, b, c, HW, zk) + i);
             const unsigned long long o = ((unsigned long long)b * C + c) * HW + i;
             VecF<V> a;
 #pragma unroll
             for (int j = 0; j < V; j++) {
-                t.v[j] = fmaxf(fmaf(t.v[j] - mean, sc, sh), 0.f);
+                t.v[j] = fmaxf(fmaf(__fmul_rn(t.v[j], zk) - mean, sc, sh), 0.f);      // (the product rounded by itself, as when it was stored)
                 a.v[j] = t.v[j] * drop_factor(d, o + j);
             }
             if (s_out) t.st(s_out + o);
             if (a_out) a.st(a_out + o);
         });
     };
-    if (vec4_ok(HW, zbs)) body(std::integral_constant<int, 4>{});
+    if (vec4_ok(HW, zc.u ? 0 : zbs)) body(std::integral_constant<int, 4>{});
     else body(std::integral_constant<int, 1>{});
 }
 
@@ -393,7 +414,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const float* __restrict__
                                                        const float* __restrict__ z, long long zbs, int B, int C, int HW,
                                                        const float* __restrict__ saved, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, Drop d, float* __restrict__ g_out,
-                                                       double* __restrict__ sums) {
+                                                       double* __restrict__ sums, ZCat zc) {
     __shared__ double red[4];
     const int c = blockIdx.y;
     const float mean = saved[2 * c], invstd = saved[2 * c + 1];
@@ -404,7 +425,10 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const float* __restrict__
         constexpr int V = decltype(VT)::value;
         plane_loop<V>(B, HW, [&](int b, int i) {
             const long long ci = (long long)c * HW + i;
-            const VecF<V> zt = VecF<V>::ld(z + b * zbs + ci);
+            float zk;
+            VecF<V> zt = VecF<V>::ld(z_plane(z, zbs, zc, b, c, HW, zk) + i);
+#pragma unroll
+            for (int j = 0; j < V; j++) zt.v[j] = __fmul_rn(zt.v[j], zk);
             const unsigned long long o = ((unsigned long long)b * C + c) * HW + i;
             VecF<V> g, ta, tb;
             if (gA) ta = VecF<V>::ld(gA + b * gAbs + ci);
@@ -423,7 +447,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const float* __restrict__
             if (g_out) g.st(g_out + o);
         });
     };
-    if (vec4_ok(HW, zbs, gA ? gAbs : 0, gB ? gBbs : 0)) body(std::integral_constant<int, 4>{});
+    if (vec4_ok(HW, zc.u ? 0 : zbs, gA ? gAbs : 0, gB ? gBbs : 0)) body(std::integral_constant<int, 4>{});
     else body(std::integral_constant<int, 1>{});
     const double t1 = block_sum(s1, red);
     const double t2 = block_sum(s2, red);
@@ -440,7 +464,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply2(const float* __restrict__
                                                        int HW, const float* __restrict__ saved, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, Drop d, const double* __restrict__ sums,
                                                        double N, double* __restrict__ acc_gamma, double* __restrict__ acc_beta,
-                                                       float* __restrict__ dz) {
+                                                       float* __restrict__ dz, ZCat zc) {
     const int c = blockIdx.y;
     const float mean = saved[2 * c], invstd = saved[2 * c + 1];
     const float ga = gamma[c], be = beta[c];
@@ -454,7 +478,10 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply2(const float* __restrict__
         constexpr int V = decltype(VT)::value;
         plane_loop<V>(B, HW, [&](int b, int i) {
             const long long ci = (long long)c * HW + i;
-            const VecF<V> zt = VecF<V>::ld(z + b * zbs + ci);
+            float zk;
+            VecF<V> zt = VecF<V>::ld(z_plane(z, zbs, zc, b, c, HW, zk) + i);
+#pragma unroll
+            for (int j = 0; j < V; j++) zt.v[j] = __fmul_rn(zt.v[j], zk);
             const unsigned long long o = ((unsigned long long)b * C + c) * HW + i;
             VecF<V> g, ta, tb;
             if (gA) ta = VecF<V>::ld(gA + b * gAbs + ci);
@@ -471,7 +498,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply2(const float* __restrict__
             g.st(dz + o);
         });
     };
-    if (vec4_ok(HW, zbs, gA ? gAbs : 0, gB ? gBbs : 0)) body(std::integral_constant<int, 4>{});
+    if (vec4_ok(HW, zc.u ? 0 : zbs, gA ? gAbs : 0, gB ? gBbs : 0)) body(std::integral_constant<int, 4>{});
     else body(std::integral_constant<int, 1>{});
 }
 
@@ -581,7 +608,8 @@ __global__ void __launch_bounds__(256) k_att_fwd(const float* __restrict__ pool,
 }
 
 // cat[b][c][:] = u[b][c][:] * att[b][c];  cat[b][C+c][:] = skip[b][c][:];  sums[c2][0..1] += sum cat, sum cat^2 (the
-// BatchNorm statistics of the concatenated tensor, so that no separate pass reads it again).  grid (chunks, 2C)
+// BatchNorm statistics of the concatenated tensor).  cat == nullptr: the statistics only (the tensor itself is never
+// written: ZCat).  grid (chunks, 2C)
 __global__ void __launch_bounds__(256) k_scale_concat(const float* __restrict__ u, const float* __restrict__ att,
                                                       const float* __restrict__ skip, int B, int C, int HW,
                                                       float* __restrict__ cat, double* __restrict__ sums) {
@@ -602,7 +630,7 @@ __global__ void __launch_bounds__(256) k_scale_concat(const float* __restrict__ 
                 s1 += (double)t.v[j];
                 s2 += (double)t.v[j] * (double)t.v[j];
             }
-            t.st(cat + ((long long)b * 2 * C + c2) * HW + i);
+            if (cat) t.st(cat + ((long long)b * 2 * C + c2) * HW + i);
         });
     };
     if (vec4_ok(HW)) body(std::integral_constant<int, 4>{});

@@ -77,7 +77,7 @@ struct ConvLayer {
     int64_t w1 = 0, w2 = 0;          // attention weights
     // workspace (float offsets)
     int64_t z = 0, s = 0, a = 0;     // enc: raw conv out, relu(bn), dropout(relu(bn))
-    int64_t u = 0, cat = 0, din_next = 0, pool = 0, hid = 0, att = 0, dpool = 0, da = 0;   // dec
+    int64_t u = 0, din_next = 0, pool = 0, hid = 0, att = 0, dpool = 0, da = 0;   // dec
     int64_t gz = 0, ga = 0;          // enc grads: g/dz (C,HW), grad wrt a
     int64_t gu = 0, gcat = 0, gdin = 0;   // dec grads: du, g/dcat, grad wrt this layer's input
 };
@@ -287,23 +287,25 @@ void bn_stats(unet_engine* e, const Bn& bn, const float* x, long long bs, int B,
     chan_sums(e, x, bs, B, bn.C, HW, e->dsum(bn.sums), 2, 1);
 }
 
+const ZCat kNoCat{nullptr, nullptr, nullptr, 0};
+
 void bn_act(unet_engine* e, const Bn& bn, const float* z, long long zbs, int B, int HW, bool train, Drop d, float* s_out,
-            float* a_out) {
+            float* a_out, const ZCat& zc = kNoCat) {
     hipLaunchKernelGGL(k_bn_act, ew_grid(B, bn.C, HW), dim3(256), 0, e->stream, z, zbs, B, bn.C, HW, e->f(bn.saved),
                        e->Bf(bn.rmean), e->Bf(bn.rvar), kEps, train ? 2 : 1, e->dsum(bn.sums), (double)B * HW, kMomentum,
-                       e->P(bn.gamma), e->P(bn.beta), d, s_out, a_out);
+                       e->P(bn.gamma), e->P(bn.beta), d, s_out, a_out, zc);
 }
 
 // BatchNorm+ReLU(+dropout) backward: g_io holds dz on return
 void bn_backward(unet_engine* e, const Bn& bn, const float* gA, long long gAbs, const float* gB, long long gBbs,
-                 const float* z, long long zbs, int B, int HW, Drop d, float* g_io) {
+                 const float* z, long long zbs, int B, int HW, Drop d, float* g_io, const ZCat& zc = kNoCat) {
     // pass 1 only sums; pass 2 forms the masked gradient again from gA / gB / z and writes dz (g_io may alias neither input:
     // the callers pass distinct buffers)
     hipLaunchKernelGGL(k_bn_bwd_reduce, red_grid(B, bn.C, HW), dim3(256), 0, e->stream, gA, gAbs, gB, gBbs, z, zbs, B, bn.C,
-                       HW, e->f(bn.saved), e->P(bn.gamma), e->P(bn.beta), d, (float*)nullptr, e->dsum(bn.bsums));
+                       HW, e->f(bn.saved), e->P(bn.gamma), e->P(bn.beta), d, (float*)nullptr, e->dsum(bn.bsums), zc);
     hipLaunchKernelGGL(k_bn_bwd_apply2, ew_grid(B, bn.C, HW), dim3(256), 0, e->stream, gA, gAbs, gB, gBbs, z, zbs, B, bn.C, HW,
                        e->f(bn.saved), e->P(bn.gamma), e->P(bn.beta), d, e->dsum(bn.bsums), (double)B * HW, e->gacc(bn.gamma),
-                       e->gacc(bn.beta), g_io);
+                       e->gacc(bn.beta), g_io, zc);
 }
 
 // small Linear layers: the whole weight matrix is a few 16x16 tiles' worth (see the include of kernels_gemm.h above)
@@ -504,11 +506,13 @@ int forward(unet_engine* e, const float* x, int B, bool train) {
         hipLaunchKernelGGL(k_pool, dim3(B * C), dim3(256), 0, e->stream, e->f(L.u), HW, e->f(L.pool));
         hipLaunchKernelGGL(k_att_fwd, dim3(B), dim3(256), (size_t)(2 * C + 2 * L.R) * sizeof(float), e->stream, e->f(L.pool),
                            C, L.R, e->P(L.w1), e->P(L.w2), e->f(L.att), e->f(L.hid));
-        // the concat pass also accumulates the BatchNorm sums of what it writes
-        hipLaunchKernelGGL(k_scale_concat, red_grid(B, 2 * C, HW), dim3(256), 0, e->stream, e->f(L.u), e->f(L.att), skip, B, C,
-                           HW, e->f(L.cat), train ? e->dsum(L.bn.sums) : nullptr);
+        // the concatenated tensor (gated u | skip) is never written: a pass over its two sources leaves the BatchNorm sums
+        // (training only), and BatchNorm + ReLU + dropout reads the same two sources (ZCat)
+        if (train)
+            hipLaunchKernelGGL(k_scale_concat, red_grid(B, 2 * C, HW), dim3(256), 0, e->stream, e->f(L.u), e->f(L.att), skip, B, C,
+                               HW, (float*)nullptr, e->dsum(L.bn.sums));
         const Drop d = make_drop(e, SITE_DEC_CONV + j, train);
-        bn_act(e, L.bn, e->f(L.cat), (long long)2 * C * HW, B, HW, train, d, nullptr, e->f(L.din_next));
+        bn_act(e, L.bn, nullptr, 0, B, HW, train, d, nullptr, e->f(L.din_next), ZCat{e->f(L.u), e->f(L.att), skip, C});
         cur = e->f(L.din_next);
     }
     UHIP_TRY(hipGetLastError());
@@ -576,8 +580,9 @@ int backward(unet_engine* e, const float* x, int B) {
         // gdin is the gradient wrt dropout(relu(bn(cat_{j-1})))
         ConvLayer& Pv = e->dec[j - 1];
         const int Cp = Pv.g.Cl, HWp = Pv.g.Hl * Pv.g.Wl;
-        bn_backward(e, Pv.bn, e->f(L.gdin), (long long)2 * Cp * HWp, nullptr, 0, e->f(Pv.cat), (long long)2 * Cp * HWp, B,
-                    HWp, make_drop(e, SITE_DEC_CONV + (j - 1), true), e->f(Pv.gcat));
+        bn_backward(e, Pv.bn, e->f(L.gdin), (long long)2 * Cp * HWp, nullptr, 0, nullptr, 0, B, HWp,
+                    make_drop(e, SITE_DEC_CONV + (j - 1), true), e->f(Pv.gcat),
+                    ZCat{e->f(Pv.u), e->f(Pv.att), e->f(e->enc[n - 2 - (j - 1)].s), Cp});
         // first half of gcat: through the attention gate to u; second half: into the encoder skip (read in place later)
         hipLaunchKernelGGL(k_att_da, dim3(B * Cp), dim3(256), 0, e->stream, e->f(Pv.gcat), e->f(Pv.u), Cp, HWp, e->f(Pv.da));
         hipLaunchKernelGGL(k_att_bwd, dim3(B), dim3(256), (size_t)(3 * Cp + 4 * Pv.R) * sizeof(float), e->stream,
@@ -826,7 +831,7 @@ int unet_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spe
         const int64_t nl = B * L.g.Cl * L.g.Hl * L.g.Wl, ns = B * L.g.Cs * L.g.Hs * L.g.Ws;
         L.u = F32(nl), L.gu = F32(nl), L.gdin = F32(ns);
         if (L.has_skip) {
-            L.cat = F32(2 * nl), L.din_next = F32(2 * nl), L.gcat = F32(2 * nl);
+            L.din_next = F32(2 * nl), L.gcat = F32(2 * nl);
             L.pool = F32(3 * B * L.g.Cl), L.hid = F32(2 * B * L.R), L.att = F32(B * L.g.Cl);
             L.dpool = F32(2 * B * L.g.Cl), L.da = F32(B * L.g.Cl);
             carve_saved(L.bn);
@@ -1014,7 +1019,7 @@ int unet_debug_read(unet_engine* e, const char* what, float* out, int64_t count)
         const std::string k = std::to_string(j);
         table["dec_u" + k] = e->dec[j].u, table["dec_gu" + k] = e->dec[j].gu, table["dec_gdin" + k] = e->dec[j].gdin;
         if (e->dec[j].has_skip)
-            table["dec_cat" + k] = e->dec[j].cat, table["att" + k] = e->dec[j].att, table["dec_din" + std::to_string(j + 1)] = e->dec[j].din_next,
+            table["att" + k] = e->dec[j].att, table["dec_din" + std::to_string(j + 1)] = e->dec[j].din_next,
             table["dec_gcat" + k] = e->dec[j].gcat;
     }
     for (int k = 0; k < 4; k++) table["fc_h" + std::to_string(k)] = e->fc[k].h, table["fc_a" + std::to_string(k)] = e->fc[k].a;
