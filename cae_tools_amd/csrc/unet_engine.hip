@@ -1,5 +1,12 @@
 // unet_engine.hip — host side of the UNET path: tensor table, workspace carving, launch sequence and the
 // extern "C" ABI declared in include/cae_unet.h.
+//
+// Which kernels a layer runs (conv_down / conv_up / conv_wgrad / lin_fwd / lin_bwd below decide, in this order):
+//   4x4 / s2 / p1 layers with <= 4 channels on the large side (the image end)   kernels_unet_thin.h   (patch in LDS, weights in registers)
+//   ... with maps 16 / 32 / 64 / 128 wide and channel counts multiples of 4 / 8   kernels_unet_patch.h  (patch in LDS, weight tiles in LDS)
+//   any other 4x4 / s2 / p1 layer                                                 kernels_unet_mfma.h   (im2col tile engine)
+//   anything else, and everything when `specialised` is off                      kernels_unet.h        (shape-generic)
+//   Linear layers: both sides <= 1024 -> the ConvAE path's 16x16 GEMM (ugemm); batch <= 64 -> kernels_unet_lin.h; else the tile engine.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
