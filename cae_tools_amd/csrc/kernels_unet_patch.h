@@ -215,8 +215,17 @@ __global__ void __launch_bounds__(256) k_pup(Geom g, const float* __restrict__ S
     float* Sp = Wt + 2 * TN * kPupWP;                        // [8][planep]
     const PatchShape sh = pup_shape(g);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int b = blockIdx.x / sh.tiles, q0 = (blockIdx.x - b * sh.tiles) * sh.R;
-    const int n0 = blockIdx.y * TN, py = blockIdx.z;
+    // the row parities and the row tiles of one pixel tile read the same patch rows: dealt to the same XCD (linear id mod 8) one
+    // right after the other, so that the later ones find them in that L2
+    int bx = blockIdx.x, by = blockIdx.y, py = blockIdx.z;
+    if (RBN == 1 && (gridDim.x & 7) == 0) {      // (measured: -8 % for the 32-row tiles, +9 % for the 64-row ones, which keep launch order)
+        const int i = bx + gridDim.x * (by + gridDim.y * py), j = i >> 3, nc = 2 * gridDim.y, c = j % nc;
+        bx = (j / nc) * 8 + (i & 7);
+        py = c & 1;
+        by = c >> 1;
+    }
+    const int b = bx / sh.tiles, q0 = (bx - b * sh.tiles) * sh.R;
+    const int n0 = by * TN;
     const int W4 = g.Ws >> 2, prow = sh.R + 2;
     const int lunits = kPupCG * prow * W4;                   // <= 768 float4s
 
