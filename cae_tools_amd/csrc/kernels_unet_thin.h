@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(256) k_thin_down(Geom g, const float* __restri
 inline int thin_down_tpw(const Geom& g) {
     static const int tpw_env = getenv("CAE_THIN_DOWN_TPW") ? atoi(getenv("CAE_THIN_DOWN_TPW")) : 0;   // env: tuning runs only
     const int tiles = thin_shape(g).tiles;
-    const int tpw = tpw_env > 0 ? tpw_env : 4;
+    const int tpw = tpw_env > 0 ? tpw_env : 8;
     return tpw > tiles ? tiles : tpw;
 }
 template <int RBN>
