@@ -178,21 +178,25 @@ def test_ragged_epoch_matches_oracle_batch_by_batch():
     np.testing.assert_allclose(np.array(got), np.array(want), rtol=3e-5)
 
 
-def test_mfma_path_at_medium_size_against_oracle_and_generic_kernels():
-    """wide layers (32 / 64 / 96 channels: full tiles, a 64-row tile and a partly filled 128-row tile), odd batch,
-    64x64 maps, dropout on: MFMA convolutions + GEMM Linear layers against the CPU oracle and the generic kernels"""
+@pytest.mark.parametrize("size,chans,fc,latent,B", [(64, [32, 64, 96], 24, 6, 5), (128, [16, 32, 64, 72], 20, 5, 3)],
+                         ids=["64px_32-64-96", "128px_16-32-64-72"])
+def test_mfma_path_at_medium_size_against_oracle_and_generic_kernels(size, chans, fc, latent, B):
+    """wide layers, odd batch, dropout on: the specialised kernels (image-end layers from an LDS patch with the weights in
+    registers, wide layers from a patch with weight tiles, the im2col tile engine for what those do not take, the Linear
+    kernels) against the CPU oracle and the generic kernels.  64 px, 32 / 64 / 96 channels: full tiles, a 64-row tile and a
+    partly filled 128-row tile, maps 32 / 16 / 8 wide.  128 px, 16 / 32 / 64 / 72 channels: maps 64 ... 8 wide, a 16-channel
+    image-end layer, channel counts the patch kernels take (32, 64) next to ones they leave to the tile engine (72)"""
     from cae_tools_amd.models.unet import Decoder, Encoder, unet_layer_spec
     from cae_tools_amd.unet_engine import UnetEngine
     from oracle import unet_oracle as uo
-    spec = unet_layer_spec(3, 3, (64, 64), [32, 64, 96])
-    (fc, latent, B) = (24, 6, 5)
+    spec = unet_layer_spec(3, 3, (size, size), chans)
     torch.manual_seed(123)
     enc = Encoder(spec.get_input_layers(), latent, fc)
     dec = Decoder(spec.get_output_layers(), latent, fc)
     g = torch.Generator().manual_seed(9)
-    x = torch.rand((B, 3, 64, 64), generator=g)
-    t = torch.rand((B, 3, 64, 64), generator=g)
-    m = (torch.rand((B, 1, 64, 64), generator=g) < 0.85).float()
+    x = torch.rand((B, 3, size, size), generator=g)
+    t = torch.rand((B, 3, size, size), generator=g)
+    m = (torch.rand((B, 1, size, size), generator=g) < 0.85).float()
     to64 = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     res = {}
     for specialised in (True, False):
