@@ -361,8 +361,10 @@ __global__ void __launch_bounds__(256) k_bn_act(const float* __restrict__ z, lon
                                                 float eps, int stat_mode, const double* __restrict__ sums, double N,
                                                 float momentum, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, Drop d, float* __restrict__ s_out,
-                                                float* __restrict__ a_out, ZCat zc) {
+                                                float* __restrict__ a_out, ZCat zc, double* __restrict__ skip_sums) {
+    __shared__ double red[4];
     const int c = blockIdx.y;
+    double q1 = 0, q2 = 0;       // sum s, sum s^2 (skip_sums: the decoder's BatchNorm statistics of this skip, [c][2])
     float mean, invstd;
     if (stat_mode == 2) {
         const double m = sums[2 * c] / N;
@@ -396,6 +398,7 @@ __global__ void __launch_bounds__(256) k_bn_act(const float* __restrict__ z, lon
             for (int j = 0; j < V; j++) {
                 t.v[j] = fmaxf(fmaf(__fmul_rn(t.v[j], zk) - mean, sc, sh), 0.f);      // (the product rounded by itself, as when it was stored)
                 a.v[j] = t.v[j] * drop_factor(d, o + j);
+                if (skip_sums) q1 += (double)t.v[j], q2 += (double)t.v[j] * (double)t.v[j];
             }
             if (s_out) t.st(s_out + o);
             if (a_out) a.st(a_out + o);
@@ -403,6 +406,14 @@ __global__ void __launch_bounds__(256) k_bn_act(const float* __restrict__ z, lon
     };
     if (vec4_ok(HW, zc.u ? 0 : zbs)) body(std::integral_constant<int, 4>{});
     else body(std::integral_constant<int, 1>{});
+    if (skip_sums) {
+        const double t1 = block_sum(q1, red);
+        const double t2 = block_sum(q2, red);
+        if (threadIdx.x == 0) {
+            atomicAdd(&skip_sums[2 * c], t1);
+            atomicAdd(&skip_sums[2 * c + 1], t2);
+        }
+    }
 }
 
 // backward, pass 1: g = (gA * dropmask + gB) * [bn(z) > 0]; accumulates sums[c][0..1] += sum g, sum g*xhat and, when g_out is
@@ -518,13 +529,15 @@ __global__ void __launch_bounds__(256) k_relu_drop(const float* __restrict__ h, 
 // channel attention (unet.py:23-39) and the skip concat (unet.py:157-160)
 // ---------------------------------------------------------------------------------------------
 
-// pool[b*C+c] = {mean, max, (float)argmax} of u[b][c][:].  grid (B*C)
-__global__ void __launch_bounds__(256) k_pool(const float* __restrict__ u, int HW, float* __restrict__ pool) {
+// pool[b*C+c] = {mean, max, (float)argmax} of u[b][c][:]; psum[b*C+c] = {sum u, sum u^2} (training: k_att_fwd turns them into the
+// BatchNorm sums of the gated half of the concatenated tensor).  grid (B*C)
+__global__ void __launch_bounds__(256) k_pool(const float* __restrict__ u, int HW, float* __restrict__ pool,
+                                              double* __restrict__ psum) {
     __shared__ double red[4];
     __shared__ float smax[256];
     __shared__ int sarg[256];
     const float* p = u + (size_t)blockIdx.x * HW;
-    double s = 0;
+    double s = 0, s2 = 0;
     float mx = -INFINITY;
     int am = 0x7fffffff;
     if ((HW & 3) == 0) {   // 16-byte loads; elements visited in increasing index per thread, so the first maximum is kept
@@ -535,6 +548,7 @@ __global__ void __launch_bounds__(256) k_pool(const float* __restrict__ u, int H
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 s += (double)v[j];
+                s2 += (double)v[j] * (double)v[j];
                 if (v[j] > mx) {
                     mx = v[j];
                     am = 4 * i + j;
@@ -545,6 +559,7 @@ __global__ void __launch_bounds__(256) k_pool(const float* __restrict__ u, int H
         for (int i = threadIdx.x; i < HW; i += 256) {
             const float v = p[i];
             s += (double)v;
+            s2 += (double)v * (double)v;
             if (v > mx) {
                 mx = v;
                 am = i;
@@ -554,6 +569,7 @@ __global__ void __launch_bounds__(256) k_pool(const float* __restrict__ u, int H
     smax[threadIdx.x] = mx;
     sarg[threadIdx.x] = am;
     const double t = block_sum(s, red);
+    const double t2 = psum ? block_sum(s2, red) : 0.0;      // (uniform)
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if (threadIdx.x < off) {
@@ -570,14 +586,17 @@ __global__ void __launch_bounds__(256) k_pool(const float* __restrict__ u, int H
         pool[3 * blockIdx.x + 0] = (float)(t / HW);
         pool[3 * blockIdx.x + 1] = smax[0];
         pool[3 * blockIdx.x + 2] = __int_as_float(sarg[0]);
+        if (psum) psum[2 * blockIdx.x] = t, psum[2 * blockIdx.x + 1] = t2;
     }
 }
 
-// att[b][c] = sigmoid(sum_r W2[c][r] * (relu(W1[r]·avg) + relu(W1[r]·max)));  hid[b][0..R) = W1·avg, [R..2R) = W1·max
+// att[b][c] = sigmoid(sum_r W2[c][r] * (relu(W1[r]·avg) + relu(W1[r]·max)));  hid[b][0..R) = W1·avg, [R..2R) = W1·max;
+// sums != nullptr: sums[c][0..1] += att * sum u, att^2 * sum u^2 (the gated half's BatchNorm statistics without another pass over u)
 // grid (B), block 256, dynamic LDS (2C + 2R) floats
 __global__ void __launch_bounds__(256) k_att_fwd(const float* __restrict__ pool, int C, int R, const float* __restrict__ W1,
                                                  const float* __restrict__ W2, float* __restrict__ att,
-                                                 float* __restrict__ hid) {
+                                                 float* __restrict__ hid, const double* __restrict__ psum,
+                                                 double* __restrict__ sums) {
     extern __shared__ float lds_f[];
     float* avg = lds_f;
     float* mx = lds_f + C;
@@ -603,44 +622,11 @@ __global__ void __launch_bounds__(256) k_att_fwd(const float* __restrict__ pool,
             oa = fmaf(W2[(size_t)c * R + r], fmaxf(h[r], 0.f), oa);
             om = fmaf(W2[(size_t)c * R + r], fmaxf(h[R + r], 0.f), om);
         }
-        att[(size_t)b * C + c] = 1.f / (1.f + expf(-(oa + om)));
-    }
-}
-
-// cat[b][c][:] = u[b][c][:] * att[b][c];  cat[b][C+c][:] = skip[b][c][:];  sums[c2][0..1] += sum cat, sum cat^2 (the
-// BatchNorm statistics of the concatenated tensor).  cat == nullptr: the statistics only (the tensor itself is never
-// written: ZCat).  grid (chunks, 2C)
-__global__ void __launch_bounds__(256) k_scale_concat(const float* __restrict__ u, const float* __restrict__ att,
-                                                      const float* __restrict__ skip, int B, int C, int HW,
-                                                      float* __restrict__ cat, double* __restrict__ sums) {
-    __shared__ double red[4];
-    const int c2 = blockIdx.y;
-    const bool first = c2 < C;
-    const int c = first ? c2 : c2 - C;
-    const float* src = first ? u : skip;
-    double s1 = 0, s2 = 0;
-    auto body = [&](auto VT) {
-        constexpr int V = decltype(VT)::value;
-        plane_loop<V>(B, HW, [&](int b, int i) {
-            VecF<V> t = VecF<V>::ld(src + ((long long)b * C + c) * HW + i);
-            const float k = first ? att[(long long)b * C + c] : 1.f;
-#pragma unroll
-            for (int j = 0; j < V; j++) {
-                if (first) t.v[j] *= k;
-                s1 += (double)t.v[j];
-                s2 += (double)t.v[j] * (double)t.v[j];
-            }
-            if (cat) t.st(cat + ((long long)b * 2 * C + c2) * HW + i);
-        });
-    };
-    if (vec4_ok(HW)) body(std::integral_constant<int, 4>{});
-    else body(std::integral_constant<int, 1>{});
-    if (sums) {
-        const double t1 = block_sum(s1, red);
-        const double t2 = block_sum(s2, red);
-        if (threadIdx.x == 0) {
-            atomicAdd(&sums[2 * c2], t1);
-            atomicAdd(&sums[2 * c2 + 1], t2);
+        const float a = 1.f / (1.f + expf(-(oa + om)));
+        att[(size_t)b * C + c] = a;
+        if (sums) {   // channel c of the concatenated tensor is a * u: its sums over this sample's map
+            atomicAdd(&sums[2 * c], (double)a * psum[2 * ((size_t)b * C + c)]);
+            atomicAdd(&sums[2 * c + 1], (double)a * (double)a * psum[2 * ((size_t)b * C + c) + 1]);
         }
     }
 }

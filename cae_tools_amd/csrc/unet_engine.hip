@@ -84,7 +84,7 @@ struct ConvLayer {
     int64_t w1 = 0, w2 = 0;          // attention weights
     // workspace (float offsets)
     int64_t z = 0, s = 0, a = 0;     // enc: raw conv out, relu(bn), dropout(relu(bn))
-    int64_t u = 0, din_next = 0, pool = 0, hid = 0, att = 0, dpool = 0, da = 0;   // dec
+    int64_t u = 0, din_next = 0, pool = 0, psum = 0, hid = 0, att = 0, dpool = 0, da = 0;   // dec
     int64_t gz = 0, ga = 0;          // enc grads: g/dz (C,HW), grad wrt a
     int64_t gu = 0, gcat = 0, gdin = 0;   // dec grads: du, g/dcat, grad wrt this layer's input
 };
@@ -296,14 +296,15 @@ void bn_stats(unet_engine* e, const Bn& bn, const float* x, long long bs, int B,
 
 const ZCat kNoCat{nullptr, nullptr, nullptr, 0};
 
+// skip_sums: where the sums of the ReLU output go (the skip half of a decoder layer's BatchNorm statistics), or nullptr
 void bn_act(unet_engine* e, const Bn& bn, const float* z, long long zbs, int B, int HW, bool train, Drop d, float* s_out,
-            float* a_out, const ZCat& zc = kNoCat) {
-    hipLaunchKernelGGL(k_bn_act, ew_grid(B, bn.C, HW), dim3(256), 0, e->stream, z, zbs, B, bn.C, HW, e->f(bn.saved),
-                       e->Bf(bn.rmean), e->Bf(bn.rvar), kEps, train ? 2 : 1, e->dsum(bn.sums), (double)B * HW, kMomentum,
-                       e->P(bn.gamma), e->P(bn.beta), d, s_out, a_out, zc);
+            float* a_out, const ZCat& zc = kNoCat, double* skip_sums = nullptr) {
+    // (with sums to leave, fewer and longer workgroups: red_grid)
+    hipLaunchKernelGGL(k_bn_act, skip_sums ? red_grid(B, bn.C, HW) : ew_grid(B, bn.C, HW), dim3(256), 0, e->stream, z, zbs, B, bn.C, HW,
+                       e->f(bn.saved), e->Bf(bn.rmean), e->Bf(bn.rvar), kEps, train ? 2 : 1, e->dsum(bn.sums), (double)B * HW, kMomentum,
+                       e->P(bn.gamma), e->P(bn.beta), d, s_out, a_out, zc, skip_sums);
 }
 
-// BatchNorm+ReLU(+dropout) backward: g_io holds dz on return
 void bn_backward(unet_engine* e, const Bn& bn, const float* gA, long long gAbs, const float* gB, long long gBbs,
                  const float* z, long long zbs, int B, int HW, Drop d, float* g_io, const ZCat& zc = kNoCat) {
     // pass 1 only sums; pass 2 forms the masked gradient again from gA / gB / z and writes dz (g_io may alias neither input:
@@ -483,7 +484,9 @@ int forward(unet_engine* e, const float* x, int B, bool train) {
         if (train) bn_stats(e, L.bn, e->f(L.z), (long long)g.Cs * HW, B, HW);
         const Drop d = make_drop(e, SITE_ENC_CONV + i, train);
         // the skip is the ReLU output; the next layer sees it through the dropout (unet.py:105-107)
-        bn_act(e, L.bn, e->f(L.z), (long long)g.Cs * HW, B, HW, train, d, e->f(L.s), d.on ? e->f(L.a) : nullptr);
+        // (a skip's sums are the second half of its decoder layer's BatchNorm statistics: dec[n - 2 - i], channels Cs ..)
+        double* skip_sums = (train && i < n - 1) ? e->dsum(e->dec[n - 2 - i].bn.sums) + 2 * g.Cs : nullptr;
+        bn_act(e, L.bn, e->f(L.z), (long long)g.Cs * HW, B, HW, train, d, e->f(L.s), d.on ? e->f(L.a) : nullptr, kNoCat, skip_sums);
         cur = d.on ? e->f(L.a) : e->f(L.s);
     }
     // encoder_lin / decoder_lin: Linear, BN1d, ReLU, Dropout, Linear, ReLU, Dropout (unet.py:92-100,121-129)
@@ -510,14 +513,13 @@ int forward(unet_engine* e, const float* x, int B, bool train) {
         conv_up(e, g, cur, e->P(L.w), L.wp >= 0 ? e->f(L.wp) : nullptr, e->P(L.b), e->f(L.u));
         if (!L.has_bn) break;   // last layer: sigmoid is applied by the loss / score kernels
         const float* skip = e->f(e->enc[n - 2 - j].s);
-        hipLaunchKernelGGL(k_pool, dim3(B * C), dim3(256), 0, e->stream, e->f(L.u), HW, e->f(L.pool));
+        // the concatenated tensor (gated u | skip) is never written, and in training nothing reads its sources again for the
+        // BatchNorm statistics: the pooling pass leaves sum u and sum u^2 per (b, c), the gate kernel scales them by att and
+        // att^2, and the skip half's sums came with the encoder's BatchNorm + ReLU pass
+        double* psum = reinterpret_cast<double*>(e->f(L.psum));
+        hipLaunchKernelGGL(k_pool, dim3(B * C), dim3(256), 0, e->stream, e->f(L.u), HW, e->f(L.pool), train ? psum : nullptr);
         hipLaunchKernelGGL(k_att_fwd, dim3(B), dim3(256), (size_t)(2 * C + 2 * L.R) * sizeof(float), e->stream, e->f(L.pool),
-                           C, L.R, e->P(L.w1), e->P(L.w2), e->f(L.att), e->f(L.hid));
-        // the concatenated tensor (gated u | skip) is never written: a pass over its two sources leaves the BatchNorm sums
-        // (training only), and BatchNorm + ReLU + dropout reads the same two sources (ZCat)
-        if (train)
-            hipLaunchKernelGGL(k_scale_concat, red_grid(B, 2 * C, HW), dim3(256), 0, e->stream, e->f(L.u), e->f(L.att), skip, B, C,
-                               HW, (float*)nullptr, e->dsum(L.bn.sums));
+                           C, L.R, e->P(L.w1), e->P(L.w2), e->f(L.att), e->f(L.hid), psum, train ? e->dsum(L.bn.sums) : nullptr);
         const Drop d = make_drop(e, SITE_DEC_CONV + j, train);
         bn_act(e, L.bn, nullptr, 0, B, HW, train, d, nullptr, e->f(L.din_next), ZCat{e->f(L.u), e->f(L.att), skip, C});
         cur = e->f(L.din_next);
@@ -839,7 +841,7 @@ int unet_engine_create(const cae_layer_spec* enc, int n_enc, const cae_layer_spe
         L.u = F32(nl), L.gu = F32(nl), L.gdin = F32(ns);
         if (L.has_skip) {
             L.din_next = F32(2 * nl), L.gcat = F32(2 * nl);
-            L.pool = F32(3 * B * L.g.Cl), L.hid = F32(2 * B * L.R), L.att = F32(B * L.g.Cl);
+            L.pool = F32(3 * B * L.g.Cl), L.psum = F32(4 * B * L.g.Cl), L.hid = F32(2 * B * L.R), L.att = F32(B * L.g.Cl);
             L.dpool = F32(2 * B * L.g.Cl), L.da = F32(B * L.g.Cl);
             carve_saved(L.bn);
         }
