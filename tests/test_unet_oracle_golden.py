@@ -61,3 +61,29 @@ def test_dropout_hash_properties():
     assert int(uo.dropout_key(3, 7, 201)) == 3624308049
     assert uo.dropout_keep(3, 7, 201, (2, 3, 5), 0.5).astype(int).reshape(-1).tolist() == \
         [1, 1, 0, 1, 1, 1, 0, 0, 1, 0, 1, 0, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 1]
+
+
+def test_relu_align_follows_foreign_decisions_only_near_zero():
+    """oracle.unet_oracle.ReluAlign (what lets a parity test take the ReLU decisions of the implementation under test): with the
+    oracle's own decisions nothing changes; a foreign decision is followed where the pre-activation is within tol of zero and
+    ignored anywhere else"""
+    from oracle import unet_oracle as uo
+    x = torch.tensor([[-2.0, -3e-6, 4e-6, 1.5], [0.3, -0.2, 2e-7, -1e-7]], requires_grad=True)
+    own = (x > 0).numpy()
+    with uo.ReluAlign({"site": own}) as al:
+        y = uo._relu(x, "site")
+    assert torch.equal(y, torch.relu(x)) and al.followed == {"site": 0}
+    foreign = own.copy()
+    foreign[0, 1] = True       # -3e-6: inside tol, followed (the value passes, its gradient too)
+    foreign[0, 2] = False      # +4e-6: inside tol, followed (blocked)
+    foreign[0, 0] = True       # -2.0: far from zero, ignored
+    foreign[1, 0] = False      # +0.3: far from zero, ignored
+    with uo.ReluAlign({"site": foreign}, tol=1e-5) as al:
+        y = uo._relu(x, "site")
+        other = uo._relu(x, "another site")          # no decisions for this name: plain ReLU
+    y.sum().backward()
+    assert al.followed == {"site": 2}
+    assert torch.equal(other, torch.relu(x))
+    np.testing.assert_array_equal(y.detach().numpy(), np.array([[0.0, -3e-6, 0.0, 1.5], [0.3, 0.0, 2e-7, 0.0]], dtype=np.float32))
+    np.testing.assert_array_equal(x.grad.numpy(), np.array([[0, 1, 0, 1], [1, 0, 1, 0]], dtype=np.float32))
+    assert uo._relu_hook is None
