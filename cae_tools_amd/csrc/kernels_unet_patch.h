@@ -30,8 +30,11 @@ namespace {
 typedef float patch_f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kPatchPx = 128;     // output pixels per workgroup
-constexpr int kPatchCG = 4;       // input channels per K chunk
-constexpr int kPatchWP = 64 + 4;  // pitch of the weight chunk [row][64]
+#ifndef PATCH_CG
+#define PATCH_CG 4
+#endif
+constexpr int kPatchCG = PATCH_CG;       // input channels per K chunk
+constexpr int kPatchWP = 16 * kPatchCG + 4;  // pitch of the weight chunk [row][16 CG]
 
 struct PatchShape {
     int R;        // map rows of S per tile
@@ -89,12 +92,13 @@ __global__ void __launch_bounds__(256) k_pdown(Geom g, const float* __restrict__
         l_map[i] = ok ? (((long long)b * g.Cl + cl) * g.Hl + Y) * g.Wl + 4 * c4 : -1;
     }
     const long long cplane = (long long)g.Hl * g.Wl;
-    const int wc4 = tid & 15, wr0 = tid >> 4;                // weights: column quad wc4 of rows wr0, wr0 + 16, ...
-    float4 wreg[2 * RBN], lreg[4];
+    constexpr int QW = 4 * kPatchCG, RPP = 256 / QW, NWQ = 32 * RBN / RPP;   // float4s per weight row, rows per pass, passes
+    const int wc4 = tid % QW, wr0 = tid / QW;                // weights: column quad wc4 of rows wr0, wr0 + RPP, ...
+    float4 wreg[NWQ], lreg[4];
     auto fetch = [&](int cg) {
 #pragma unroll
-        for (int i = 0; i < 2 * RBN; i++) {
-            const int n = n0 + wr0 + 16 * i;
+        for (int i = 0; i < NWQ; i++) {
+            const int n = n0 + wr0 + RPP * i;
             wreg[i] = n < g.Cs ? *reinterpret_cast<const float4*>(w + ((size_t)n * g.Cl + cg * kPatchCG) * 16 + 4 * wc4)
                                : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -105,8 +109,8 @@ __global__ void __launch_bounds__(256) k_pdown(Geom g, const float* __restrict__
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2 * RBN; i++)      // taps stored (kx0, kx2, kx1, kx3): a lane's two k values of a (channel, ky) are adjacent
-            *reinterpret_cast<float4*>(Wt + (wr0 + 16 * i) * kPatchWP + 4 * wc4) = make_float4(wreg[i].x, wreg[i].z, wreg[i].y, wreg[i].w);
+        for (int i = 0; i < NWQ; i++)      // taps stored (kx0, kx2, kx1, kx3): a lane's two k values of a (channel, ky) are adjacent
+            *reinterpret_cast<float4*>(Wt + (wr0 + RPP * i) * kPatchWP + 4 * wc4) = make_float4(wreg[i].x, wreg[i].z, wreg[i].y, wreg[i].w);
 #pragma unroll
         for (int i = 0; i < 4; i++)
             if (l_lds[i] >= 0) *reinterpret_cast<float4*>(Lp + l_lds[i]) = lreg[i];
@@ -166,7 +170,7 @@ inline void pdown_launch(const Geom& g, const float* L, const float* w, const fl
     const long long tiles = (long long)g.B * sh.tiles * rt;
     const int groups = g.Cl / kPatchCG;
     int nsplit = 1;     // few tiles and a long K: slice it so that every CU has work
-    while (tiles * nsplit < 384 && groups / (nsplit * 2) >= 4 && nsplit < 8) nsplit *= 2;
+    while (tiles * nsplit < 384 && groups / (nsplit * 2) >= 16 / kPatchCG && nsplit < 8) nsplit *= 2;
     const int gper = (groups + nsplit - 1) / nsplit;
     if (nsplit > 1) (void)hipMemsetAsync(S, 0, (size_t)g.B * g.Cs * g.Hs * g.Ws * sizeof(float), s);
     const dim3 grid((unsigned)(g.B * sh.tiles), rt, nsplit);
