@@ -10,7 +10,8 @@
 // as D[cs][t] = sum_p S[cs][p] * patch(t, p), t = (cl, ky, kx): rows = channels, columns = taps, K = pixels.  A tile is 128
 // consecutive pixels of S (128 / Ws rows); the four waves take 32 pixels each, a workgroup walks `tpw` tiles with the next
 // tile's loads in flight and the accumulators in registers, then the waves' partial sums are added in wave order through LDS
-// and leave as one fp64 atomic per value.
+// and the workgroup's Cs x 16 Cl tile goes to scratch; k_thin_fold adds the workgroups' tiles in index order (fp64): no atomics,
+// the result does not depend on timing.
 //
 // LDS images.  S tile [cs][128 + 4] floats: a lane's ds_read_b128 gives it four k steps; sixteen rows start four banks apart.
 // Patch [cl][2R + 2 rows][4 + Wl] floats: index 4 + c holds column c, indices 0-3 are zero (3 = column -1; the row's right
