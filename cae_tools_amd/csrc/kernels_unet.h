@@ -513,6 +513,56 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply2(const float* __restrict__
     else body(std::integral_constant<int, 1>{});
 }
 
+// pass 2 in the decoder's form: one workgroup per (b, c) plane of the (never written) concatenated tensor - same arithmetic per
+// element as k_bn_bwd_apply2 - which lets the gated half leave da[b][c] = sum_i dz[b][c][i] * u[b][c][i] on the way (the gate's
+// gradient; it took k_att_da another pass over dz and u).  No gB here.  grid (1, C = 2 Ch, B)
+__global__ void __launch_bounds__(256) k_bn_bwd_apply2_planes(const float* __restrict__ gA, long long gAbs, int C, int HW,
+                                                              const float* __restrict__ saved, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, Drop d, const double* __restrict__ sums,
+                                                              double N, double* __restrict__ acc_gamma, double* __restrict__ acc_beta,
+                                                              float* __restrict__ dz, ZCat zc, float* __restrict__ da) {
+    __shared__ double red[4];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float mean = saved[2 * c], invstd = saved[2 * c + 1];
+    const float ga = gamma[c], be = beta[c];
+    const float k1 = ga * invstd, sc = invstd * ga;
+    const float m1 = (float)(sums[2 * c] / N), m2 = (float)(sums[2 * c + 1] / N);
+    if (b == 0 && threadIdx.x == 0) {
+        acc_gamma[c] += sums[2 * c + 1];
+        acc_beta[c] += sums[2 * c];
+    }
+    const bool gated = c < zc.Ch;
+    const float zk = gated ? zc.att[(long long)b * zc.Ch + c] : 1.f;
+    const float* zp = gated ? zc.u + ((long long)b * zc.Ch + c) * HW : zc.skip + ((long long)b * zc.Ch + (c - zc.Ch)) * HW;
+    const float* gp = gA + b * gAbs + (long long)c * HW;
+    const unsigned long long o0 = ((unsigned long long)b * C + c) * HW;
+    float* op = dz + o0;
+    double s = 0.0;
+    auto body = [&](auto VT) {
+        constexpr int V = decltype(VT)::value;
+        for (int i = threadIdx.x * V; i < HW; i += 256 * V) {
+            const VecF<V> ut = VecF<V>::ld(zp + i), ta = VecF<V>::ld(gp + i);
+            VecF<V> g;
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                const float zv = __fmul_rn(ut.v[j], zk);
+                const float xh = (zv - mean) * invstd;
+                float gv = ta.v[j] * drop_factor(d, o0 + i + j);
+                if (!(fmaf(zv - mean, sc, be) > 0.f)) gv = 0.f;
+                g.v[j] = k1 * (gv - m1 - xh * m2);
+                if (gated) s += (double)(g.v[j] * ut.v[j]);
+            }
+            g.st(op + i);
+        }
+    };
+    if (vec4_ok(HW, gAbs)) body(std::integral_constant<int, 4>{});
+    else body(std::integral_constant<int, 1>{});
+    if (gated) {
+        const double t = block_sum(s, red);
+        if (threadIdx.x == 0) da[(size_t)b * zc.Ch + c] = (float)t;
+    }
+}
+
 // g *= dropmask * [h > 0]  (ReLU + dropout backward where there is no BatchNorm: the second Linear of each stack)
 __global__ void __launch_bounds__(256) k_relu_drop_bwd(float* __restrict__ g, const float* __restrict__ h, long long n, Drop d) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
@@ -629,28 +679,6 @@ __global__ void __launch_bounds__(256) k_att_fwd(const float* __restrict__ pool,
             atomicAdd(&sums[2 * c + 1], (double)a * (double)a * psum[2 * ((size_t)b * C + c) + 1]);
         }
     }
-}
-
-// da[b*C+c] = sum_i dcat[b][c][i] * u[b][c][i]   (dcat has 2C channels).  grid (B*C)
-__global__ void __launch_bounds__(256) k_att_da(const float* __restrict__ dcat, const float* __restrict__ u, int C, int HW,
-                                                float* __restrict__ da) {
-    __shared__ double red[4];
-    const int b = blockIdx.x / C, c = blockIdx.x - b * C;
-    const float* gp = dcat + ((size_t)b * 2 * C + c) * HW;
-    const float* up = u + (size_t)blockIdx.x * HW;
-    double s = 0;
-    if ((HW & 3) == 0) {   // 16-byte loads: both planes start on a multiple of HW floats
-        const float4* g4 = reinterpret_cast<const float4*>(gp);
-        const float4* u4 = reinterpret_cast<const float4*>(up);
-        for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
-            const float4 a = g4[i], b = u4[i];
-            s += (double)(a.x * b.x) + (double)(a.y * b.y) + (double)(a.z * b.z) + (double)(a.w * b.w);
-        }
-    } else {
-        for (int i = threadIdx.x; i < HW; i += 256) s += (double)(gp[i] * up[i]);
-    }
-    const double t = block_sum(s, red);
-    if (threadIdx.x == 0) da[blockIdx.x] = (float)t;
 }
 
 // backward of k_att_fwd for one sample per block: dpool[b*C+c] = {davg, dmax}; weight gradients by fp64 atomics.

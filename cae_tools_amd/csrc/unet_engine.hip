@@ -589,11 +589,20 @@ int backward(unet_engine* e, const float* x, int B) {
         // gdin is the gradient wrt dropout(relu(bn(cat_{j-1})))
         ConvLayer& Pv = e->dec[j - 1];
         const int Cp = Pv.g.Cl, HWp = Pv.g.Hl * Pv.g.Wl;
-        bn_backward(e, Pv.bn, e->f(L.gdin), (long long)2 * Cp * HWp, nullptr, 0, nullptr, 0, B, HWp,
-                    make_drop(e, SITE_DEC_CONV + (j - 1), true), e->f(Pv.gcat),
-                    ZCat{e->f(Pv.u), e->f(Pv.att), e->f(e->enc[n - 2 - (j - 1)].s), Cp});
-        // first half of gcat: through the attention gate to u; second half: into the encoder skip (read in place later)
-        hipLaunchKernelGGL(k_att_da, dim3(B * Cp), dim3(256), 0, e->stream, e->f(Pv.gcat), e->f(Pv.u), Cp, HWp, e->f(Pv.da));
+        // BatchNorm + ReLU + dropout backward over the (never written) concatenated tensor: pass 1 sums; pass 2, one workgroup per
+        // (b, c) plane, writes dz and - for the gated half - the gate's gradient da[b][c] = sum dz * u in the same pass.  The first
+        // half of gcat goes on through the attention gate to u, the second half into the encoder skip (read in place later)
+        {
+            const Drop dd = make_drop(e, SITE_DEC_CONV + (j - 1), true);
+            const ZCat zc{e->f(Pv.u), e->f(Pv.att), e->f(e->enc[n - 2 - (j - 1)].s), Cp};
+            const Bn& bn = Pv.bn;
+            hipLaunchKernelGGL(k_bn_bwd_reduce, red_grid(B, bn.C, HWp), dim3(256), 0, e->stream, e->f(L.gdin), (long long)2 * Cp * HWp,
+                               (const float*)nullptr, 0LL, (const float*)nullptr, 0LL, B, bn.C, HWp, e->f(bn.saved), e->P(bn.gamma),
+                               e->P(bn.beta), dd, (float*)nullptr, e->dsum(bn.bsums), zc);
+            hipLaunchKernelGGL(k_bn_bwd_apply2_planes, dim3(1, bn.C, B), dim3(256), 0, e->stream, e->f(L.gdin), (long long)2 * Cp * HWp,
+                               bn.C, HWp, e->f(bn.saved), e->P(bn.gamma), e->P(bn.beta), dd, e->dsum(bn.bsums), (double)B * HWp,
+                               e->gacc(bn.gamma), e->gacc(bn.beta), e->f(Pv.gcat), zc, e->f(Pv.da));
+        }
         hipLaunchKernelGGL(k_att_bwd, dim3(B), dim3(256), (size_t)(3 * Cp + 4 * Pv.R) * sizeof(float), e->stream,
                            e->f(Pv.pool), e->f(Pv.att), e->f(Pv.hid), e->f(Pv.da), Cp, Pv.R, e->P(Pv.w1), e->P(Pv.w2),
                            e->gacc(Pv.w1), e->gacc(Pv.w2), e->f(Pv.dpool));
