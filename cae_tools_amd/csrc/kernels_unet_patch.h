@@ -165,7 +165,9 @@ __global__ void __launch_bounds__(256) k_pdown(Geom g, const float* __restrict__
 
 inline void pdown_launch(const Geom& g, const float* L, const float* w, const float* bias, float* S, hipStream_t s) {
     const PatchShape sh = patch_shape(g);
-    const int rbn = g.Cs <= 64 ? 2 : 4;
+    // 64-row tiles where there are few pixel tiles (the deep layers): twice the workgroups without slicing K twice as fine -
+    // half the atomics, or none (101 -> 77 us and 102 -> 84 us for the encoder's 32 x 32 and 16 x 16 layers at batch 32)
+    const int rbn = (g.Cs <= 64 || (long long)g.B * sh.tiles <= 256) ? 2 : 4;
     const int TN = 32 * rbn, rt = (g.Cs + TN - 1) / TN;
     const long long tiles = (long long)g.B * sh.tiles * rt;
     const int groups = g.Cl / kPatchCG;
