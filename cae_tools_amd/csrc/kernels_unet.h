@@ -867,10 +867,10 @@ __global__ void __launch_bounds__(256) k_loss_sums(const float* __restrict__ u, 
     const float* mp = ls_src.mask ? ls_src.mask + (smp * ls_src.Cm + (ls_src.Cm == 1 ? 0 : c)) * HW : nullptr;
     const float* up = u + (size_t)bc * HW;
     double a[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
-        const double m = mp ? (double)mp[i] : 1.0;
-        const double p = (double)(apply_sigmoid ? sigmoidf(up[i]) : up[i]);
-        const double t = (double)tp[i];
+    auto one = [&](float uv, float tv, float mv) {
+        const double m = (double)mv;
+        const double p = (double)(apply_sigmoid ? sigmoidf(uv) : uv);
+        const double t = (double)tv;
         const float df = ((float)p - (float)t) * (float)m;   // the reference forms (pred - target) * mask in fp32
         a[0] += m;
         a[1] += m * p;
@@ -879,6 +879,15 @@ __global__ void __launch_bounds__(256) k_loss_sums(const float* __restrict__ u, 
         a[4] += m * t * t;
         a[5] += m * p * t;
         a[6] += (double)df * (double)df;
+    };
+    if ((HW & 3) == 0) {      // 16-byte loads (the planes start on multiples of HW floats)
+        for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < HW; i += gridDim.x * 1024) {
+            const float4 uv = *reinterpret_cast<const float4*>(up + i), tv = *reinterpret_cast<const float4*>(tp + i);
+            const float4 mv = mp ? *reinterpret_cast<const float4*>(mp + i) : make_float4(1.f, 1.f, 1.f, 1.f);
+            one(uv.x, tv.x, mv.x), one(uv.y, tv.y, mv.y), one(uv.z, tv.z, mv.z), one(uv.w, tv.w, mv.w);
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) one(up[i], tp[i], mp ? mp[i] : 1.f);
     }
     for (int k = 0; k < 7; k++) {
         const double t = block_sum(a[k], red);

@@ -544,8 +544,10 @@ int loss_forward(unet_engine* e, int which, const int32_t* perm, int64_t start, 
     double* ls = reinterpret_cast<double*>(e->ws + e->off_ls);
     UHIP_TRY(hipMemsetAsync(ls, 0, (size_t)B * C * 8 * sizeof(double), e->stream));
     const LossSrc src = loss_src(e, which, perm, start);
-    int chunks = (HW + 256 * 16 - 1) / (256 * 16);
-    if (chunks > 32) chunks = 32;
+    // (seven workgroup-wide fp64 sums end every workgroup: about 768 of them, each a long slice of its plane)
+    static const int ls_wgs = getenv("CAE_UNET_LSWGS") ? atoi(getenv("CAE_UNET_LSWGS")) : 768;   // env: tuning runs only
+    int chunks = std::max(1, std::min(32, ls_wgs / std::max(1, B * C)));
+    chunks = std::min(chunks, (HW + 1023) / 1024);
     hipLaunchKernelGGL(k_loss_sums, dim3(chunks, B * C), dim3(256), 0, e->stream, e->f(L.u), 1, src, C, HW, ls);
     double* out2 = reinterpret_cast<double*>(e->ws + e->off_losses) + 2 * (size_t)slot;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, e->stream, ls, B, C, src.Cm, src.mask ? 1 : 0, e->lambda_p,
