@@ -563,10 +563,11 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply2_planes(const float* __res
     }
 }
 
-// g *= dropmask * [h > 0]  (ReLU + dropout backward where there is no BatchNorm: the second Linear of each stack)
-__global__ void __launch_bounds__(256) k_relu_drop_bwd(float* __restrict__ g, const float* __restrict__ h, long long n, Drop d) {
+// g = gin * dropmask * [h > 0]  (ReLU + dropout backward where there is no BatchNorm: the second Linear of each stack)
+__global__ void __launch_bounds__(256) k_relu_drop_bwd(float* __restrict__ g, const float* __restrict__ gin, const float* __restrict__ h,
+                                                       long long n, Drop d) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        g[i] = h[i] > 0.f ? g[i] * drop_factor(d, (unsigned long long)i) : 0.f;
+        g[i] = h[i] > 0.f ? gin[i] * drop_factor(d, (unsigned long long)i) : 0.f;
 }
 
 // a = dropout(relu(h))  (forward of the same)

@@ -135,6 +135,7 @@ struct OpDown {
 struct PackSet {
     int n;
     int Cs[8], Cl[8];
+    int thin[8];        // 1: the image-end ConvTranspose2d's order instead (kernels_unet_thin.h: taps of a (cs, cl, ky) as kx 1, 2, 3, 0)
     const float* w[8];
     float* wp[8];
     long long begin[9];
@@ -146,6 +147,10 @@ __global__ void __launch_bounds__(256) k_pack_up_weights(PackSet ps) {
         while (l + 1 < ps.n && e >= ps.begin[l + 1]) l++;
         const int Cs = ps.Cs[l], Cl = ps.Cl[l];
         const long long o = e - ps.begin[l];
+        if (ps.thin[l]) {
+            ps.wp[l][o] = ps.w[l][(o & ~3ll) + ((o + 1) & 3)];
+            continue;
+        }
         const int k = (int)(o % (Cs * 4));
         const long long r = o / (Cs * 4);
         const int cl = (int)(r % Cl), z = (int)(r / Cl);

@@ -377,15 +377,11 @@ inline void thin_down_launch(const Geom& g, const float* L, const float* w, cons
 // 2T x 4 x CL outputs in registers: one 8-byte load per lane, row and channel instead of the nine 4-byte gathers per position
 // of k_up_thin, the next channel's rows in flight.  The four output columns of a lane are two float pairs so that the
 // multiply-adds are packed (v_pk_fma_f32): pair0 += (b, b) * (w1, w2) + (a, c) * (w3, w0), pair1 += (c, c) * (w1, w2) + (b, d) *
-// (w3, w0) for the inputs a b c d = columns 2l-1 .. 2l+2; wq holds the taps in that order (k_pack_thin_up).
+// (w3, w0) for the inputs a b c d = columns 2l-1 .. 2l+2; wq holds the taps in that order (k_pack_up_weights, thin entry).
 // grid B * Hs / T waves (4 per workgroup), block 256
 typedef float thin_f2 __attribute__((ext_vector_type(2)));
 
-// wq[((cs * CL + cl) * 4 + ky) * 4 + {0,1,2,3}] = w[cs][cl][ky][{1,2,3,0}]
-__global__ void __launch_bounds__(256) k_pack_thin_up(int n, const float* __restrict__ w, float* __restrict__ wq) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) wq[i] = w[(i & ~3) + ((i + 1) & 3)];
-}
+// (wq[((cs * CL + cl) * 4 + ky) * 4 + {0,1,2,3}] = w[cs][cl][ky][{1,2,3,0}]: written by k_pack_up_weights, kernels_unet_mfma.h)
 
 __device__ __forceinline__ float thin_from_right(float v) {      // lane i <- lane i + 1 (lane 63: 0)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
@@ -460,10 +456,8 @@ inline bool thin_up_geom(const Geom& g) {
     return g.kh == 4 && g.kw == 4 && g.s == 2 && g.p == 1 && g.Hl == 2 * g.Hs && g.Wl == 2 * g.Ws && g.Cl >= 1 && g.Cl <= 4 &&
            g.Ws == 128 && g.Hs % 2 == 0 && (long long)g.B * g.Cs * g.Hs * g.Ws < (1ll << 31);
 }
-// wq: room for Cs * Cl * 16 floats
-inline void thin_up_launch(const Geom& g, const float* S, const float* w, float* wq, const float* bias, float* L, hipStream_t s) {
-    const int n = g.Cs * g.Cl * 16;
-    hipLaunchKernelGGL(k_pack_thin_up, dim3((n + 255) / 256), dim3(256), 0, s, n, w, wq);
+// wq: the layer's weights in k_thin_up's order (k_pack_up_weights, thin entry)
+inline void thin_up_launch(const Geom& g, const float* S, const float* wq, const float* bias, float* L, hipStream_t s) {
     static const int t_env = getenv("CAE_THIN_UP_T") ? atoi(getenv("CAE_THIN_UP_T")) : 2;   // env: tuning runs only
     const int T = (t_env == 4 && g.Hs % 4 == 0) ? 4 : 2;
     const int waves = g.B * (g.Hs / T);

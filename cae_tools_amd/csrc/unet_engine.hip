@@ -214,7 +214,7 @@ void conv_down(unet_engine* e, const Geom& g, const float* L, const float* w, co
 void conv_up(unet_engine* e, const Geom& g, const float* S, const float* w, const float* wp, const float* bias, float* L) {
     static const int thin_off = getenv("CAE_UNET_THIN") ? atoi(getenv("CAE_UNET_THIN")) == 0 : 0;   // env: A/B measurements only
     if (e->specialised && !thin_off && wp && thin_up_geom(g)) {   // ... 128 columns wide: the row walk of kernels_unet_thin.h
-        thin_up_launch(g, S, w, const_cast<float*>(wp), bias, L, e->stream);
+        thin_up_launch(g, S, wp, bias, L, e->stream);
         return;
     }
     if (e->specialised && mfma_geom(g) && g.Cl <= 4) {   // a handful of output channels: streaming kernel, not a GEMM
@@ -457,7 +457,8 @@ void pack_up_weights(unet_engine* e, bool train) {
     PackSet ps;
     memset(&ps, 0, sizeof ps);
     auto add = [&](const ConvLayer& L) {
-        if (L.wp < 0 || ps.n == 8 || L.g.Cl <= 4) return;      // (Cl <= 4: kernels_unet_thin.h packs its own order)
+        if (L.wp < 0 || ps.n == 8) return;
+        ps.thin[ps.n] = L.g.Cl <= 4;                           // (the image-end layer: k_thin_up's order)
         ps.Cs[ps.n] = L.g.Cs, ps.Cl[ps.n] = L.g.Cl, ps.w[ps.n] = e->P(L.w), ps.wp[ps.n] = e->f(L.wp);
         ps.begin[ps.n + 1] = ps.begin[ps.n] + (long long)16 * L.g.Cs * L.g.Cl;
         ps.n++;
@@ -621,8 +622,7 @@ int backward(unet_engine* e, const float* x, int B) {
         if (L.has_bn) {
             bn_backward(e, L.bn, gin, L.nout, nullptr, 0, e->f(L.h), L.nout, B, 1, d, e->f(L.gh));
         } else {
-            UHIP_TRY(hipMemcpyAsync(e->f(L.gh), gin, (size_t)B * L.nout * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
-            hipLaunchKernelGGL(k_relu_drop_bwd, dim3(blocks_for((long long)B * L.nout)), dim3(256), 0, e->stream, e->f(L.gh),
+            hipLaunchKernelGGL(k_relu_drop_bwd, dim3(blocks_for((long long)B * L.nout)), dim3(256), 0, e->stream, e->f(L.gh), gin,
                                e->f(L.h), (long long)B * L.nout, d);
         }
         const float* in = k == 0 ? (make_drop(e, SITE_ENC_CONV + n - 1, true).on ? e->f(e->enc[n - 1].a) : e->f(e->enc[n - 1].s))
